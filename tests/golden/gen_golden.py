@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""
+gen_golden.py — regenerates the committed golden vectors under tests/golden/.
+
+Source of truth = Python stdlib only (big ints, hashlib.blake2b / hashlib.sha256, json), through
+oracle/pyoracle.py — an implementation independent of the reference's Rust crates, of the C
+oracle and of the HIP kernels.  The reference crate itself cannot be run (no cargo/rustc in this
+environment); its own known-answer tests are transcribed by hand in ref_kat.json (not produced
+by this script).
+
+Run from the repo root:  python tests/golden/gen_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle import pyoracle as po  # noqa: E402
+
+P, G = po.P, po.G
+
+
+def dump(name, obj):
+    with open(os.path.join(HERE, name), "w") as f:
+        json.dump(obj, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print("wrote", name)
+
+
+def elems_digest(vals):
+    """sha256 over the canonical 16-byte little-endian encoding of each element"""
+    h = hashlib.sha256()
+    for v in vals:
+        h.update(int(v).to_bytes(16, "little"))
+    return h.hexdigest()
+
+
+def main():
+    # ---- Blake2b-512 (RFC 7693) ----
+    msgs = [b"", b"abc", bytes(16), bytes(128), bytes(range(128)), bytes(range(16)), bytes(129), bytes(range(256)),
+            hashlib.sha256(b"seed0").digest() * 4, hashlib.sha256(b"seed1").digest() * 4]
+    dump("blake2b_vectors.json", [{"msg": m.hex(), "digest": po.blake2b512(m).hex()} for m in msgs])
+
+    # ---- SHA-256 ----
+    smsgs = [b"", b"abc", bytes(55), bytes(56), bytes(64), bytes(range(200))]
+    dump("sha256_vectors.json", [{"msg": m.hex(), "digest": po.sha256(m).hex()} for m in smsgs])
+
+    # ---- Merkle roots over leaf_i = blake2b(le16(i)) (G2 leaf hash of the integers 0..L-1) ----
+    mk = []
+    for L in (1, 2, 4, 64, 1024, 4096):
+        leaves = po.hash_leaves(range(L))
+        e = {"L": L, "root": po.merkle_commit(leaves).hex()}
+        if L == 64:
+            e["open"] = {str(i): [h.hex() for h in po.merkle_open(leaves, i)] for i in (0, 1, 37, 63)}
+        mk.append(e)
+    dump("merkle_roots.json", mk)
+
+    # ---- field-op table over the edge set ----
+    R = (1 << 128) % P
+    edge = [0, 1, 2, P - 1, P - 2, 2**64 - 1, 2**64, 2**127, R, 2**64 - 3, 2**64 - 2, 2**32, 2**96 + 5, (P + 1) // 2, G]
+    rows = []
+    for a in edge:
+        for b in edge:
+            rows.append({"a": str(a), "b": str(b), "add": str(po.fp_add(a, b)), "sub": str(po.fp_sub(a, b)),
+                         "mul": str(po.fp_mul(a, b)), "div": (str(po.fp_div(a, b)) if b else None)})
+    dump("field_ops.json", {"p": str(P), "rows": rows})
+
+    # ---- roots of unity + NTT of x_j = j+1 ----
+    nt = {"generator": str(G), "roots_of_unity": {str(k): str(po.root_of_unity(k)) for k in (0, 1, 2, 3, 10, 16, 20, 24, 119)}, "ntt": []}
+    for n in (2, 4, 8, 1024):
+        x = [j + 1 for j in range(n)]
+        y = po.ntt(x)
+        assert po.ntt(y, inverse=True) == x
+        if n <= 8:
+            assert y == po.ntt_naive(x)
+        nt["ntt"].append({"n": n, "out": [str(v) for v in y]} if n <= 8 else
+                         {"n": n, "out_head": [str(v) for v in y[:8]], "out_sha256": elems_digest(y)})
+    # bigger sizes: checksum only (inputs = SplitMix64 elements)
+    for log_n, seed in ((12, 12), (13, 13), (16, 2)):
+        x = po.splitmix_elems(seed, 1 << log_n)
+        y = po.ntt(x)
+        nt["ntt"].append({"n": 1 << log_n, "seed": seed, "in_sha256": elems_digest(x), "out_head": [str(v) for v in y[:4]],
+                          "out_sha256": elems_digest(y)})
+    dump("ntt_vectors.json", nt)
+
+    # ---- coset LDE ----
+    lde = []
+    for log_n, seed in ((4, 9), (8, 1), (14, 7)):
+        c = po.splitmix_elems(seed, 1 << log_n)
+        y = po.coset_lde(c, 2, G)
+        if log_n == 4:
+            assert y == po.coset_eval_naive(c, 2, G)
+        lde.append({"log_n": log_n, "log_expansion": 2, "seed": seed, "offset": str(G), "out_head": [str(v) for v in y[:4]],
+                    "out_sha256": elems_digest(y)})
+    dump("lde_vectors.json", lde)
+
+    # ---- fold ----
+    cw = po.splitmix_elems(11, 64)
+    alpha, off, om = po.splitmix_elems(12, 1)[0], G, po.root_of_unity(6)
+    dump("fold_vectors.json", {"seed": 11, "L": 64, "alpha": str(alpha), "offset": str(off), "omega": str(om),
+                               "out": [str(v) for v in po.fri_fold(cw, alpha, off, om)]})
+
+    # ---- sampling (G3) ----
+    dump("sample_vectors.json", [{"digest": d.hex(), "alpha": str(po.sample(d))} for d in
+                                 (bytes(32), bytes([255] * 32), po.sha256(b"x"), po.sha256(b"y"), bytes(range(32)))])
+
+    # ---- full C1 transcript: N = 2^10, expansion 4, 17 colinearity tests, offset g, seed 1 ----
+    for name, N, seed in (("fri_c1.json", 1 << 10, 1), ("fri_n4096.json", 1 << 12, 4), ("fri_n16384.json", 1 << 14, 1000)):
+        cw = po.splitmix_elems(seed, N)
+        ps = po.ProofStream()
+        roots, alphas, last = po.fri_commit(cw, 4, 17, G, ps)
+        ser = ps.serialize()
+        obj = {"N": N, "seed": seed, "expansion": 4, "num_colinearity_tests": 17, "offset": str(G),
+               "num_rounds": len(roots), "roots": [r.hex() for r in roots], "alphas": [str(a) for a in alphas],
+               "last_codeword_sha256": elems_digest(last), "last_len": len(last),
+               "stream_sha256": hashlib.sha256(ser).hexdigest(), "stream_len": len(ser),
+               "final_fiat_shamir": ps.prover_fiat_shamir().hex()}
+        if N == 1 << 10:
+            obj["last_codeword"] = [str(v) for v in last]
+            obj["stream"] = ser.decode()
+        dump(name, obj)
+
+    # ---- C2: n = 2^16 coefficients -> LDE N = 2^18 -> Merkle root (seed 2) ----
+    c = po.splitmix_elems(2, 1 << 16)
+    y = po.coset_lde(c, 2, G)
+    dump("c2_lde_merkle.json", {"log_n": 16, "log_expansion": 2, "seed": 2, "offset": str(G), "lde_sha256": elems_digest(y),
+                                "ntt_sha256": elems_digest(po.ntt(c)), "merkle_root": po.merkle_commit_elems(y).hex()})
+
+
+if __name__ == "__main__":
+    main()
