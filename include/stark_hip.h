@@ -1,0 +1,175 @@
+/*
+ * stark_hip.h — C ABI of libstark_hip.so: the MI355X (gfx950) implementation of the FRI-commit hot
+ * path of the `stark-anat` crate (greged93/stark-anatomy).  This is the drop-in boundary: every
+ * entry point below is what a Rust `extern "C"` block in the reference crate would bind (see
+ * INTEGRATION.md for the binding), and cites the reference item (file:line under
+ * /root/reference/src) it replaces.  The reference has no FFI of its own: the
+ * boundary is its public Rust API, restated here over plain pointers and sizes.
+ *
+ * Conventions
+ *  - Field element = canonical value in [0,p), p = 1 + 407*2^119 (field.rs:15), as little-endian
+ *    u128 = uint64_t[2] {lo, hi} (== Rust `u128::to_le_bytes`, what `FieldElement::value()`
+ *    returns, field.rs:52-54).  Arrays are contiguous, 16 B per element.
+ *  - Hash = 64 bytes (merkle.rs:5 `Hash = [u8; 64]`, `MerkleHash::as_bytes`, merkle.rs:22-24).
+ *  - Every function returns int32_t status: SH_OK or a negative SH_E* code; sh_last_error()
+ *    gives a thread-local message.  Nothing throws or unwinds across this boundary.  Contract
+ *    violations that `panic!`/`assert!` in the reference (non-power-of-two leaf count
+ *    merkle.rs:36, index out of range merkle.rs:75, division by zero field.rs:101-103) come back
+ *    as SH_EINVAL / SH_EBOUNDS / SH_EDIVZERO so the Rust shim can re-raise the same panic.
+ *  - `sh_*`      : caller-owned HOST buffers; data is copied to the GPU, computed there, copied back.
+ *    `sh_dev_*`  : caller-owned DEVICE buffers (hipMalloc / sh_dev_alloc / torch tensor data_ptr) on
+ *                  the context's device; work is enqueued on the context's stream; functions that
+ *                  return host results (roots, status flags) synchronise that stream.
+ *  - There is NO CPU fallback: every compute entry point fails with SH_EHIP when no gfx950 device
+ *    is usable.  Host-only helpers are listed separately at the end.
+ *  - Threading: calls on one sh_ctx must be serialised by the caller; distinct contexts (one per
+ *    GPU / thread) are independent (the reference is single-threaded plain data).
+ */
+#ifndef STARK_HIP_H
+#define STARK_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SH_OK        0
+#define SH_EINVAL   (-1)  /* null pointer, zero / non-power-of-two length, unsupported size   */
+#define SH_EDIVZERO (-2)  /* field.rs:101-103 "Cannot divide by zero"                        */
+#define SH_EHIP     (-3)  /* HIP runtime error or no usable gfx950 device                     */
+#define SH_ENOMEM   (-4)
+#define SH_ECALLBACK (-5) /* transcript callback returned non-zero                            */
+#define SH_EBOUNDS  (-6)  /* index out of range (merkle.rs:75; proof_stream.rs:30-32)         */
+#define SH_EPARSE   (-7)  /* proof_stream.rs:43 serde_json error on deserialize               */
+
+typedef struct sh_ctx sh_ctx;
+
+const char* sh_last_error(void);
+const char* sh_version(void);
+
+/* ---------------- context / device memory ---------------- */
+/* `hip_stream` may be NULL (the context creates its own stream) or a hipStream_t the caller owns
+ * (e.g. torch.cuda.current_stream().cuda_stream) on `device`. */
+int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out);
+int32_t sh_ctx_destroy(sh_ctx* ctx);
+int32_t sh_ctx_sync(sh_ctx* ctx);
+int32_t sh_ctx_device(sh_ctx* ctx, int32_t* device);
+int32_t sh_dev_alloc(sh_ctx* ctx, size_t bytes, void** dptr);
+int32_t sh_dev_free(sh_ctx* ctx, void* dptr);
+int32_t sh_dev_upload(sh_ctx* ctx, void* dptr, const void* host, size_t bytes);
+int32_t sh_dev_download(sh_ctx* ctx, void* host, const void* dptr, size_t bytes);
+
+/* ---------------- field, batched (field.rs) ----------------
+ * out[i] = a[i] (+,-,*) b[i]  — `impl Add/Sub/Mul for FieldElement`, field.rs:57-95.
+ * sh_fp_div: out[i] = a[i] / b[i] — field.rs:97-114; SH_EDIVZERO if any b[i] == 0 (outputs then
+ * unspecified).  sh_fp_inv: out[i] = 1 / a[i].  Inputs must be canonical (as `FieldElement::new`
+ * guarantees, field.rs:30-35); sh_fp_new reduces arbitrary u128 values first. */
+int32_t sh_fp_new(sh_ctx* ctx, const uint64_t* x, uint64_t* out, size_t n);
+int32_t sh_fp_add(sh_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int32_t sh_fp_sub(sh_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int32_t sh_fp_mul(sh_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int32_t sh_fp_div(sh_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int32_t sh_fp_inv(sh_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n);
+int32_t sh_dev_fp_add(sh_ctx* ctx, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n);
+int32_t sh_dev_fp_sub(sh_ctx* ctx, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n);
+int32_t sh_dev_fp_mul(sh_ctx* ctx, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n);
+int32_t sh_dev_fp_div(sh_ctx* ctx, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n);
+int32_t sh_dev_fp_inv(sh_ctx* ctx, const uint64_t* d_a, uint64_t* d_out, size_t n);
+
+/* ---------------- NTT / coset LDE (not in the reference) ----------------
+ * In place, natural order in and out: X[k] = sum_j x[j]·w^(jk), w = g^(2^119 / n),
+ * g = 85408008396924667383611388730472331217; inverse uses w^-1 and scales by n^-1.
+ * Built only from field.rs Add/Sub/Mul semantics.  1 <= 2^log_n, log_n <= SH_MAX_LOG_N. */
+#define SH_MAX_LOG_N 28
+int32_t sh_ntt(sh_ctx* ctx, uint64_t* data, uint32_t log_n, int32_t inverse);
+int32_t sh_dev_ntt(sh_ctx* ctx, uint64_t* d_data, uint32_t log_n, int32_t inverse);
+/* out[i] = f(offset·w_N^i), i in [0, n << log_expansion), f = sum_j coeffs[j] X^j. */
+int32_t sh_coset_lde(sh_ctx* ctx, const uint64_t* coeffs, uint32_t log_n, uint32_t log_expansion,
+                     const uint64_t offset[2], uint64_t* out);
+int32_t sh_dev_coset_lde(sh_ctx* ctx, const uint64_t* d_coeffs, uint32_t log_n, uint32_t log_expansion,
+                         const uint64_t offset[2], uint64_t* d_out);
+
+/* ---------------- Merkle (merkle.rs) ----------------
+ * sh_merkle_commit == `MerkleTree::commit(&[MerkleHash]).root`, merkle.rs:35-68: Blake2b-512 over
+ * adjacent pairs H(left||right), bottom-up; L must be a power of two (else SH_EINVAL, merkle.rs:36);
+ * L == 1 -> root == leaf (merkle.rs:48,62). `leaves` = L×64 bytes of already-hashed leaves. */
+int32_t sh_merkle_commit(sh_ctx* ctx, const uint8_t* leaves, size_t L, uint8_t root[64]);
+int32_t sh_dev_merkle_commit(sh_ctx* ctx, const uint8_t* d_leaves, size_t L, uint8_t root[64]);
+/* leaf hash of a field element: out[i] = Blake2b512(value_i.to_le_bytes()). */
+int32_t sh_hash_leaves(sh_ctx* ctx, const uint64_t* elems, size_t L, uint8_t* out);
+int32_t sh_dev_hash_leaves(sh_ctx* ctx, const uint64_t* d_elems, size_t L, uint8_t* d_out);
+/* fused: root of the tree whose leaves are sh_hash_leaves(elems) (what one FRI round commits to). */
+int32_t sh_merkle_commit_elems(sh_ctx* ctx, const uint64_t* elems, size_t L, uint8_t root[64]);
+int32_t sh_dev_merkle_commit_elems(sh_ctx* ctx, const uint64_t* d_elems, size_t L, uint8_t root[64]);
+/* `MerkleTree::open(index)`, merkle.rs:70-108: path[0] = sibling leaf … path[log2 L − 1] = sibling
+ * of the root's child; *path_len = log2 L.  SH_EBOUNDS if index >= L or L < 2 (merkle.rs:75,104). */
+int32_t sh_merkle_open(sh_ctx* ctx, const uint8_t* leaves, size_t L, size_t index, uint8_t* path, size_t* path_len);
+
+/* ---------------- FRI split-and-fold ----------------
+ * out[i] = 2^-1·((1 + alpha/(offset·omega^i))·cw[i] + (1 − alpha/(offset·omega^i))·cw[L/2+i]),
+ * i in [0, L/2); omega must be the primitive L-th root w_L (checked). */
+int32_t sh_fri_fold(sh_ctx* ctx, const uint64_t* cw, size_t L, const uint64_t alpha[2],
+                    const uint64_t offset[2], const uint64_t omega[2], uint64_t* out);
+int32_t sh_dev_fri_fold(sh_ctx* ctx, const uint64_t* d_cw, size_t L, const uint64_t alpha[2],
+                        const uint64_t offset[2], const uint64_t omega[2], uint64_t* d_out);
+
+/* ---------------- FRI commit driver ----------------
+ * for r in 0..R: root_r = merkle(leafhash(cw_r)); cb(root_r) -> alpha_r; cw_{r+1} = fold(cw_r).
+ * R = sh_fri_num_rounds(N, expansion, num_colinearity_tests); the last round's codeword (length
+ * N >> (R-1)) is returned in the clear.  The transcript stays on the host: the callback receives
+ * every root in order and (when want_alpha != 0) must return the challenge, so the caller's
+ * `ProofStream` (proof_stream.rs:25-27, 51-56) remains authoritative and byte-identical. */
+typedef struct {
+    uint32_t expansion;                 /* 4 in every reference configuration            */
+    uint32_t num_colinearity_tests;     /* 17                                            */
+    uint64_t offset[2];                 /* coset offset, canonical; g by convention      */
+} sh_fri_params;
+typedef int32_t (*sh_transcript_cb)(void* user, uint32_t round, const uint8_t root[64],
+                                    int32_t want_alpha, uint64_t alpha_out[2]);
+uint32_t sh_fri_num_rounds(size_t N, uint32_t expansion, uint32_t num_colinearity_tests);
+int32_t sh_fri_commit(sh_ctx* ctx, const uint64_t* codeword, size_t N, const sh_fri_params* params,
+                      sh_transcript_cb cb, void* user, uint8_t* roots_out /* R×64 */,
+                      uint64_t* last_codeword_out /* (N >> (R-1)) elems */, size_t* last_len);
+/* device-resident codeword; `d_codeword` is not modified. */
+int32_t sh_dev_fri_commit(sh_ctx* ctx, const uint64_t* d_codeword, size_t N, const sh_fri_params* params,
+                          sh_transcript_cb cb, void* user, uint8_t* roots_out,
+                          uint64_t* last_codeword_out, size_t* last_len);
+
+/* ---------------- ProofStream (proof_stream.rs) — host side, tiny, byte-exact ----------------
+ * Items are held as their compact serde_json fragments (what `serialize` observes,
+ * proof_stream.rs:38-40, 67-69).  The FRI item type is
+ *   enum ProofItem { MerkleRoot(MerkleHash), Codeword(Vec<u128>) }   (serde externally tagged). */
+typedef struct sh_proofstream sh_proofstream;
+int32_t sh_proofstream_new(sh_proofstream** out);                                      /* Default, proof_stream.rs:17 */
+int32_t sh_proofstream_free(sh_proofstream* ps);
+int32_t sh_proofstream_push_json(sh_proofstream* ps, const uint8_t* json, size_t len); /* push, :25-27 (any S) */
+int32_t sh_proofstream_push_merkle_root(sh_proofstream* ps, const uint8_t root[64]);
+int32_t sh_proofstream_push_codeword(sh_proofstream* ps, const uint64_t* elems, size_t n);
+int32_t sh_proofstream_len(sh_proofstream* ps, size_t* n_items, size_t* read_index);
+int32_t sh_proofstream_pull(sh_proofstream* ps, const uint8_t** json, size_t* len);    /* pull, :29-36; SH_EBOUNDS */
+int32_t sh_proofstream_serialize(sh_proofstream* ps, uint8_t* out, size_t cap, size_t* needed); /* :38-40 */
+int32_t sh_proofstream_deserialize(const uint8_t* bytes, size_t len, sh_proofstream** out);     /* :42-49; SH_EPARSE */
+int32_t sh_proofstream_prover_fiat_shamir(sh_proofstream* ps, uint8_t out[32]);        /* :51-56 */
+int32_t sh_proofstream_verifier_fiat_shamir(sh_proofstream* ps, uint8_t out[32]);      /* :58-64 */
+/* FRI commit against a library ProofStream: pushes each root, samples alpha = sample(prover_fiat_shamir())
+ * (G3) and finally pushes the last codeword. */
+int32_t sh_fri_commit_proofstream(sh_ctx* ctx, const uint64_t* codeword, size_t N, const sh_fri_params* params,
+                                  sh_proofstream* ps, uint8_t* roots_out, uint64_t* last_codeword_out, size_t* last_len);
+int32_t sh_dev_fri_commit_proofstream(sh_ctx* ctx, const uint64_t* d_codeword, size_t N, const sh_fri_params* params,
+                                      sh_proofstream* ps, uint8_t* roots_out, uint64_t* last_codeword_out, size_t* last_len);
+
+/* ---------------- host-only scalar helpers (no GPU involved; used by the driver and the shim) ---------------- */
+int32_t sh_sha256(const uint8_t* in, size_t len, uint8_t out[32]);                      /* crate sha2, proof_stream.rs:52-55 */
+int32_t sh_blake2b512(const uint8_t* in, size_t len, uint8_t out[64]);                  /* crate blake2, merkle.rs:134-136   */
+int32_t sh_merkle_verify(const uint8_t root[64], const uint8_t leaf[64], const uint8_t* path, size_t path_len,
+                         size_t index, int32_t* ok);                                   /* merkle.rs:110-154 */
+int32_t sh_sample_field(const uint8_t digest[32], uint64_t out[2]);                     /* G3 */
+int32_t sh_root_of_unity(uint32_t log_n, uint64_t out[2]);                              /* G1 */
+int32_t sh_generator(uint64_t out[2]);                                                  /* G1 */
+/* scalar field ops: op 0 add, 1 sub, 2 mul, 3 div, 4 pow (true modular) — FieldElement operators for single values */
+int32_t sh_fp_scalar(int32_t op, const uint64_t a[2], const uint64_t b[2], uint64_t out[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

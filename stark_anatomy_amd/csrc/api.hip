@@ -1,0 +1,592 @@
+// api.hip — the C ABI of include/stark_hip.h: context, device buffers, and the host drivers that
+// sequence the gfx950 kernels (field batch ops, NTT/LDE, Merkle commit, FRI fold and FRI commit).
+// No entry point here computes a result on the CPU: without a usable device they return SH_EHIP.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+#include "../../include/stark_hip.h"
+#include "host_internal.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+int32_t sh_fail(int32_t code, const char* msg) { g_last_error = msg ? msg : ""; return code; }
+int32_t sh_failf(int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                           \
+    do {                                                                                                       \
+        hipError_t _e = (expr);                                                                                \
+        if (_e != hipSuccess) return sh_failf(SH_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define SHCHK(expr) do { int32_t _rc = (expr); if (_rc != SH_OK) return _rc; } while (0)
+
+// ------------------------------------------------------------------ context
+#define NUM_SCRATCH 6
+enum { SCR_IO_A = 0, SCR_IO_B = 1, SCR_IO_C = 2, SCR_WORK = 3, SCR_DIG_A = 4, SCR_DIG_B = 5 };
+struct sh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void* scratch[NUM_SCRATCH] = {};
+    size_t scratch_bytes[NUM_SCRATCH] = {};
+    uint32_t* d_flag = nullptr;
+    digest64* d_root = nullptr;
+    uint8_t* h_pinned = nullptr;                 // 256 B of pinned host memory (root / flag mailbox)
+    std::map<uint32_t, fp*> tw_cache;            // key = log_n*2 + inverse
+};
+
+static int32_t ensure_scratch(sh_ctx* c, int slot, size_t bytes, void** out) {
+    if (c->scratch_bytes[slot] < bytes) {
+        if (c->scratch[slot]) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipFree(c->scratch[slot]));
+            c->scratch[slot] = nullptr; c->scratch_bytes[slot] = 0;
+        }
+        size_t want = (bytes + 255) & ~(size_t)255;
+        HIPCHK(hipMalloc(&c->scratch[slot], want));
+        c->scratch_bytes[slot] = want;
+    }
+    *out = c->scratch[slot];
+    return SH_OK;
+}
+
+static inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+static inline uint32_t ilog2(size_t x) { uint32_t l = 0; while (((size_t)1 << l) < x) ++l; return l; }
+static inline fp fp_load_host(const uint64_t v[2]) { return fp_from_u64x2(v[0], v[1]); }
+static inline void fp_store_host(uint64_t v[2], fp a) { v[0] = fp_lo64(a); v[1] = fp_hi64(a); }
+static inline bool fp_is_canonical(fp a) { return fp_to_u128(a) < fp_prime_u128(); }
+
+// G1: g = 85408008396924667383611388730472331217 = 0x4040fbed12ee470f_b5038f9c18f6f7d1, order 2^119
+static inline fp host_generator() { return fp_from_u64x2(0xb5038f9c18f6f7d1ULL, 0x4040fbed12ee470fULL); }
+static fp host_root_of_unity(uint32_t log_n) {
+    fp w = fp_to_mont(host_generator());
+    for (uint32_t i = log_n; i < 119; ++i) w = mont_mul(w, w);
+    return fp_from_mont(w);
+}
+
+// [lo | hi] Montgomery-form power table of the (inverse) n-th root of unity, cached per context.
+static int32_t get_twiddles(sh_ctx* c, uint32_t log_n, bool inverse, const fp** out) {
+    const uint32_t key = log_n * 2 + (inverse ? 1 : 0);
+    auto it = c->tw_cache.find(key);
+    if (it != c->tw_cache.end()) { *out = it->second; return SH_OK; }
+    const size_t n = (size_t)1 << log_n;
+    const size_t lo_n = n < ((size_t)1 << NTT_TW_LO_BITS) ? n : ((size_t)1 << NTT_TW_LO_BITS);
+    const size_t hi_n = (n >> NTT_TW_LO_BITS) ? (n >> NTT_TW_LO_BITS) : 1;
+    std::vector<fp> t(lo_n + hi_n);
+    fp w = host_root_of_unity(log_n);
+    if (inverse) w = fp_inv(w);
+    const fp wm = fp_to_mont(w);
+    fp acc = fp_mont_one();
+    for (size_t i = 0; i < lo_n; ++i) { t[i] = acc; acc = mont_mul(acc, wm); }
+    fp big = wm;
+    for (uint32_t i = 0; i < NTT_TW_LO_BITS; ++i) big = mont_mul(big, big);   // w^4096
+    acc = fp_mont_one();
+    for (size_t i = 0; i < hi_n; ++i) { t[lo_n + i] = acc; acc = mont_mul(acc, big); }
+    fp* d = nullptr;
+    HIPCHK(hipMalloc(&d, t.size() * sizeof(fp)));
+    hipError_t e = hipMemcpyAsync(d, t.data(), t.size() * sizeof(fp), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(d); return sh_failf(SH_EHIP, "twiddle upload failed: %s", hipGetErrorString(e)); }
+    c->tw_cache[key] = d;
+    *out = d;
+    return SH_OK;
+}
+
+extern "C" {
+
+const char* sh_last_error(void) { return g_last_error.c_str(); }
+const char* sh_version(void) { return "stark_hip 0.1 (gfx950)"; }
+
+int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out) {
+    if (!out) return sh_fail(SH_EINVAL, "sh_ctx_create: null out");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return sh_failf(SH_EHIP, "sh_ctx_create: no HIP device available (%s); libstark_hip has no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= count) return sh_failf(SH_EINVAL, "sh_ctx_create: device %d out of range [0,%d)", device, count);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return sh_failf(SH_EHIP, "sh_ctx_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    sh_ctx* c = new (std::nothrow) sh_ctx();
+    if (!c) return sh_fail(SH_ENOMEM, "sh_ctx_create: out of memory");
+    c->device = device;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return sh_failf(SH_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    e = hipMalloc(&c->d_flag, 256);
+    if (e == hipSuccess) e = hipMalloc(&c->d_root, 256);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_pinned, 256, hipHostMallocDefault);
+    if (e != hipSuccess) { sh_ctx_destroy(c); return sh_failf(SH_EHIP, "context allocation failed: %s", hipGetErrorString(e)); }
+    *out = c;
+    return SH_OK;
+}
+int32_t sh_ctx_destroy(sh_ctx* c) {
+    if (!c) return SH_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->tw_cache) (void)hipFree(kv.second);
+    for (int i = 0; i < NUM_SCRATCH; ++i) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->d_root) (void)hipFree(c->d_root);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SH_OK;
+}
+#define CTXCHK(c)                                                          \
+    do {                                                                   \
+        if (!(c)) return sh_fail(SH_EINVAL, "null sh_ctx");                \
+        HIPCHK(hipSetDevice((c)->device));                                 \
+    } while (0)
+
+int32_t sh_ctx_sync(sh_ctx* c) { CTXCHK(c); HIPCHK(hipStreamSynchronize(c->stream)); return SH_OK; }
+int32_t sh_ctx_device(sh_ctx* c, int32_t* device) { if (!c || !device) return sh_fail(SH_EINVAL, "null pointer"); *device = c->device; return SH_OK; }
+int32_t sh_dev_alloc(sh_ctx* c, size_t bytes, void** dptr) {
+    CTXCHK(c);
+    if (!dptr) return sh_fail(SH_EINVAL, "sh_dev_alloc: null out");
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 16));
+    return SH_OK;
+}
+int32_t sh_dev_free(sh_ctx* c, void* dptr) { CTXCHK(c); if (dptr) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(dptr)); } return SH_OK; }
+int32_t sh_dev_upload(sh_ctx* c, void* dptr, const void* host, size_t bytes) {
+    CTXCHK(c);
+    if (!bytes) return SH_OK;
+    if (!dptr || !host) return sh_fail(SH_EINVAL, "sh_dev_upload: null pointer");
+    HIPCHK(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SH_OK;
+}
+int32_t sh_dev_download(sh_ctx* c, void* host, const void* dptr, size_t bytes) {
+    CTXCHK(c);
+    if (!bytes) return SH_OK;
+    if (!dptr || !host) return sh_fail(SH_EINVAL, "sh_dev_download: null pointer");
+    HIPCHK(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SH_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ field batch ops
+static int32_t dev_fp_op(sh_ctx* c, int op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n) {
+    CTXCHK(c);
+    if (n == 0) return SH_OK;
+    const bool needs_b = (op == FPOP_ADD || op == FPOP_SUB || op == FPOP_MUL || op == FPOP_DIV);
+    if (!d_a || !d_out || (needs_b && !d_b)) return sh_fail(SH_EINVAL, "field op: null pointer");
+    const bool checks = (op == FPOP_DIV || op == FPOP_INV);
+    if (checks) HIPCHK(hipMemsetAsync(c->d_flag, 0, 4, c->stream));
+    HIPCHK(launch_fp_binop(op, (const fp*)d_a, (const fp*)d_b, (fp*)d_out, n, c->d_flag, c->stream));
+    if (checks) {
+        HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (*(volatile uint32_t*)c->h_pinned) return sh_fail(SH_EDIVZERO, "Cannot divide by zero");   // field.rs:102
+    }
+    return SH_OK;
+}
+static int32_t host_fp_op(sh_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    CTXCHK(c);
+    if (n == 0) return SH_OK;
+    const bool needs_b = (op == FPOP_ADD || op == FPOP_SUB || op == FPOP_MUL || op == FPOP_DIV);
+    if (!a || !out || (needs_b && !b)) return sh_fail(SH_EINVAL, "field op: null pointer");
+    void *da, *db = nullptr, *dout;
+    SHCHK(ensure_scratch(c, SCR_IO_A, n * 16, &da));
+    SHCHK(ensure_scratch(c, SCR_IO_C, n * 16, &dout));
+    HIPCHK(hipMemcpyAsync(da, a, n * 16, hipMemcpyHostToDevice, c->stream));
+    if (needs_b) {
+        SHCHK(ensure_scratch(c, SCR_IO_B, n * 16, &db));
+        HIPCHK(hipMemcpyAsync(db, b, n * 16, hipMemcpyHostToDevice, c->stream));
+    }
+    SHCHK(dev_fp_op(c, op, (const uint64_t*)da, (const uint64_t*)db, (uint64_t*)dout, n));
+    HIPCHK(hipMemcpyAsync(out, dout, n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SH_OK;
+}
+
+// ------------------------------------------------------------------ NTT / LDE
+static int32_t dev_ntt(sh_ctx* c, fp* d_data, uint32_t log_n, bool inverse) {
+    if (log_n > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "ntt: log_n %u > %d", log_n, SH_MAX_LOG_N);
+    const size_t n = (size_t)1 << log_n;
+    const fp* tw;
+    SHCHK(get_twiddles(c, log_n, inverse, &tw));
+    void* scratch;
+    SHCHK(ensure_scratch(c, SCR_WORK, n * sizeof(fp), &scratch));
+    NttPlan plan;
+    ntt_make_plan(log_n, &plan);
+    fp scale = fp_mont_one();
+    if (inverse) scale = fp_to_mont(fp_inv(fp_from_u64x2((uint64_t)n, 0)));
+    HIPCHK(launch_ntt(plan, d_data, (fp*)scratch, tw, scale, inverse, c->stream));
+    return SH_OK;
+}
+
+// ------------------------------------------------------------------ Merkle
+// Reduce `count` (power of two) digests at `cur` to the root in c->d_root.  `cur` is not modified.
+static int32_t reduce_digests(sh_ctx* c, const digest64* cur, size_t count) {
+    void *bufA, *bufB;
+    if (count > MERKLE_TAIL_MAX) {
+        SHCHK(ensure_scratch(c, SCR_DIG_B, (count >> 1) * sizeof(digest64), &bufB));
+        bufA = nullptr;
+        bool use_b = true;
+        while (count > MERKLE_TAIL_MAX) {
+            uint32_t lg = ilog2(count);
+            uint32_t K = lg - 9 < 3 ? lg - 9 : 3;                 // leave >= 512 nodes for the LDS tail
+            digest64* out;
+            if (use_b) out = (digest64*)bufB;
+            else {
+                if (!bufA) SHCHK(ensure_scratch(c, SCR_DIG_A, (count >> K) * sizeof(digest64), &bufA));
+                out = (digest64*)bufA;
+            }
+            HIPCHK(launch_node_subtree(cur, out, count >> K, K, c->stream));
+            cur = out; count >>= K; use_b = !use_b;
+        }
+    }
+    HIPCHK(launch_merkle_tail(cur, c->d_root, count, c->stream));
+    return SH_OK;
+}
+static uint32_t leaf_subtree_k(uint32_t log_L) {
+    // enough lanes to fill the chip first (>= 2^18 lanes), then deeper per-lane subtrees
+    uint32_t K = log_L > 18 ? log_L - 18 : 0;
+    return K > 3 ? 3 : K;
+}
+// root of merkle(leafhash(elems[0..L))) -> c->d_root (enqueued, not synchronised)
+static int32_t merkle_root_from_elems(sh_ctx* c, const fp* d_elems, size_t L) {
+    if (L == 1) { HIPCHK(launch_hash_leaves(d_elems, c->d_root, 1, c->stream)); return SH_OK; }
+    const uint32_t K = leaf_subtree_k(ilog2(L));
+    void* dig;
+    SHCHK(ensure_scratch(c, SCR_DIG_A, (L >> K) * sizeof(digest64), &dig));
+    HIPCHK(launch_leaf_subtree(d_elems, (digest64*)dig, L >> K, K, c->stream));
+    return reduce_digests(c, (const digest64*)dig, L >> K);
+}
+static int32_t fetch_root(sh_ctx* c, uint8_t root[64]) {
+    HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_root, 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(root, c->h_pinned, 64);
+    return SH_OK;
+}
+
+// ------------------------------------------------------------------ FRI
+static int32_t check_params(const sh_fri_params* p, fp* offset) {
+    if (!p) return sh_fail(SH_EINVAL, "fri: null params");
+    if (p->expansion == 0) return sh_fail(SH_EINVAL, "fri: expansion must be >= 1");
+    *offset = fp_load_host(p->offset);
+    if (!fp_is_canonical(*offset) || fp_is_zero(*offset)) return sh_fail(SH_EINVAL, "fri: offset must be a non-zero canonical field element");
+    return SH_OK;
+}
+static int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_params* prm, sh_transcript_cb cb, void* user,
+                              uint8_t* roots_out, uint64_t* last_out, size_t* last_len) {
+    CTXCHK(c);
+    if (!d_cw || !cb || !roots_out || !last_out || !last_len) return sh_fail(SH_EINVAL, "fri_commit: null pointer");
+    if (!is_pow2(N)) return sh_fail(SH_EINVAL, "fri_commit: N must be a power of two");
+    const uint32_t log_N = ilog2(N);
+    if (log_N > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "fri_commit: N > 2^%d", SH_MAX_LOG_N);
+    fp off;
+    SHCHK(check_params(prm, &off));
+    const uint32_t R = sh_fri_num_rounds(N, prm->expansion, prm->num_colinearity_tests);
+    const fp* cur = d_cw;
+    size_t L = N;
+    if (R > 0) {
+        const fp* tw_inv;
+        SHCHK(get_twiddles(c, log_N, true, &tw_inv));
+        void *bufX = nullptr, *bufY = nullptr;
+        if (R > 1) SHCHK(ensure_scratch(c, SCR_IO_A, (N / 2) * sizeof(fp), &bufX));
+        if (R > 2) SHCHK(ensure_scratch(c, SCR_IO_B, (N / 4) * sizeof(fp), &bufY));
+        const fp inv2 = fp_inv(fp_make(2, 0, 0, 0));
+        uint8_t root[64];
+        SHCHK(merkle_root_from_elems(c, cur, L));
+        SHCHK(fetch_root(c, root));
+        for (uint32_t r = 0; r < R; ++r) {
+            memcpy(roots_out + 64 * (size_t)r, root, 64);
+            const int32_t want = (r + 1 < R) ? 1 : 0;
+            uint64_t alpha_w[2] = {0, 0};
+            if (cb(user, r, root, want, alpha_w) != 0) return sh_failf(SH_ECALLBACK, "fri_commit: transcript callback failed in round %u", r);
+            if (!want) break;
+            const fp alpha = fp_load_host(alpha_w);
+            if (!fp_is_canonical(alpha)) return sh_fail(SH_EINVAL, "fri_commit: callback returned a non-canonical alpha");
+            // c0 = alpha · 2^-1 · offset^-1, kept in Montgomery form for the kernel
+            const fp c0 = fp_mul(fp_mul(alpha, inv2), fp_inv(off));
+            const size_t half = L / 2;
+            fp* next = (fp*)((r & 1) ? bufY : bufX);
+            uint32_t K = leaf_subtree_k(ilog2(half));
+            void* dig;
+            SHCHK(ensure_scratch(c, SCR_DIG_A, (half >> K) * sizeof(digest64), &dig));
+            HIPCHK(launch_fold_leaf_subtree(cur, L, fp_to_mont(c0), tw_inv, log_N, r, next, (digest64*)dig, K, c->stream));
+            SHCHK(reduce_digests(c, (const digest64*)dig, half >> K));
+            SHCHK(fetch_root(c, root));
+            cur = next; L = half;
+            off = fp_mul(off, off);
+        }
+    }
+    HIPCHK(hipMemcpyAsync(last_out, cur, L * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *last_len = L;
+    return SH_OK;
+}
+
+struct PsCbState { sh_proofstream* ps; };
+static int32_t ps_callback(void* user, uint32_t, const uint8_t root[64], int32_t want_alpha, uint64_t alpha_out[2]) {
+    PsCbState* st = (PsCbState*)user;
+    if (sh_proofstream_push_merkle_root(st->ps, root) != SH_OK) return 1;        // proof_stream.rs:25
+    if (want_alpha) {
+        uint8_t dig[32];
+        if (sh_proofstream_prover_fiat_shamir(st->ps, dig) != SH_OK) return 1;    // proof_stream.rs:51
+        if (sh_sample_field(dig, alpha_out) != SH_OK) return 1;                  // G3
+    }
+    return 0;
+}
+
+extern "C" {
+
+int32_t sh_fp_new(sh_ctx* c, const uint64_t* x, uint64_t* out, size_t n) { return host_fp_op(c, FPOP_NEW, x, nullptr, out, n); }
+int32_t sh_fp_add(sh_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return host_fp_op(c, FPOP_ADD, a, b, out, n); }
+int32_t sh_fp_sub(sh_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return host_fp_op(c, FPOP_SUB, a, b, out, n); }
+int32_t sh_fp_mul(sh_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return host_fp_op(c, FPOP_MUL, a, b, out, n); }
+int32_t sh_fp_div(sh_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return host_fp_op(c, FPOP_DIV, a, b, out, n); }
+int32_t sh_fp_inv(sh_ctx* c, const uint64_t* a, uint64_t* out, size_t n) { return host_fp_op(c, FPOP_INV, a, nullptr, out, n); }
+int32_t sh_dev_fp_add(sh_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return dev_fp_op(c, FPOP_ADD, a, b, out, n); }
+int32_t sh_dev_fp_sub(sh_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return dev_fp_op(c, FPOP_SUB, a, b, out, n); }
+int32_t sh_dev_fp_mul(sh_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return dev_fp_op(c, FPOP_MUL, a, b, out, n); }
+int32_t sh_dev_fp_div(sh_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return dev_fp_op(c, FPOP_DIV, a, b, out, n); }
+int32_t sh_dev_fp_inv(sh_ctx* c, const uint64_t* a, uint64_t* out, size_t n) { return dev_fp_op(c, FPOP_INV, a, nullptr, out, n); }
+
+int32_t sh_dev_ntt(sh_ctx* c, uint64_t* d_data, uint32_t log_n, int32_t inverse) {
+    CTXCHK(c);
+    if (!d_data) return sh_fail(SH_EINVAL, "sh_dev_ntt: null pointer");
+    return dev_ntt(c, (fp*)d_data, log_n, inverse != 0);
+}
+int32_t sh_ntt(sh_ctx* c, uint64_t* data, uint32_t log_n, int32_t inverse) {
+    CTXCHK(c);
+    if (!data) return sh_fail(SH_EINVAL, "sh_ntt: null pointer");
+    if (log_n > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "sh_ntt: log_n %u > %d", log_n, SH_MAX_LOG_N);
+    const size_t bytes = ((size_t)1 << log_n) * 16;
+    void* d;
+    SHCHK(ensure_scratch(c, SCR_IO_A, bytes, &d));
+    HIPCHK(hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, c->stream));
+    SHCHK(dev_ntt(c, (fp*)d, log_n, inverse != 0));
+    HIPCHK(hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SH_OK;
+}
+int32_t sh_dev_coset_lde(sh_ctx* c, const uint64_t* d_coeffs, uint32_t log_n, uint32_t log_expansion, const uint64_t offset[2], uint64_t* d_out) {
+    CTXCHK(c);
+    if (!d_coeffs || !offset || !d_out) return sh_fail(SH_EINVAL, "sh_dev_coset_lde: null pointer");
+    if (log_n + log_expansion > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "sh_dev_coset_lde: log_n + log_expansion > %d", SH_MAX_LOG_N);
+    const fp off = fp_load_host(offset);
+    if (!fp_is_canonical(off)) return sh_fail(SH_EINVAL, "sh_dev_coset_lde: non-canonical offset");
+    const size_t n = (size_t)1 << log_n, N = n << log_expansion;
+    HIPCHK(launch_coset_scale_pad((const fp*)d_coeffs, n, off, (fp*)d_out, N, c->stream));
+    return dev_ntt(c, (fp*)d_out, log_n + log_expansion, false);
+}
+int32_t sh_coset_lde(sh_ctx* c, const uint64_t* coeffs, uint32_t log_n, uint32_t log_expansion, const uint64_t offset[2], uint64_t* out) {
+    CTXCHK(c);
+    if (!coeffs || !offset || !out) return sh_fail(SH_EINVAL, "sh_coset_lde: null pointer");
+    if (log_n + log_expansion > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "sh_coset_lde: log_n + log_expansion > %d", SH_MAX_LOG_N);
+    const size_t n = (size_t)1 << log_n, N = n << log_expansion;
+    void *din, *dout;
+    SHCHK(ensure_scratch(c, SCR_IO_A, n * 16, &din));
+    SHCHK(ensure_scratch(c, SCR_IO_B, N * 16, &dout));
+    HIPCHK(hipMemcpyAsync(din, coeffs, n * 16, hipMemcpyHostToDevice, c->stream));
+    SHCHK(sh_dev_coset_lde(c, (const uint64_t*)din, log_n, log_expansion, offset, (uint64_t*)dout));
+    HIPCHK(hipMemcpyAsync(out, dout, N * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SH_OK;
+}
+
+int32_t sh_dev_merkle_commit(sh_ctx* c, const uint8_t* d_leaves, size_t L, uint8_t root[64]) {
+    CTXCHK(c);
+    if (!d_leaves || !root) return sh_fail(SH_EINVAL, "sh_dev_merkle_commit: null pointer");
+    if (!is_pow2(L)) return sh_fail(SH_EINVAL, "sh_merkle_commit: leaf count must be a power of two (merkle.rs:36)");
+    if (L == 1) {                                                  // merkle.rs:48,62: root == leaf
+        HIPCHK(hipMemcpyAsync(c->h_pinned, d_leaves, 64, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(root, c->h_pinned, 64);
+        return SH_OK;
+    }
+    SHCHK(reduce_digests(c, (const digest64*)d_leaves, L));
+    return fetch_root(c, root);
+}
+int32_t sh_merkle_commit(sh_ctx* c, const uint8_t* leaves, size_t L, uint8_t root[64]) {
+    CTXCHK(c);
+    if (!leaves || !root) return sh_fail(SH_EINVAL, "sh_merkle_commit: null pointer");
+    if (!is_pow2(L)) return sh_fail(SH_EINVAL, "sh_merkle_commit: leaf count must be a power of two (merkle.rs:36)");
+    void* d;
+    SHCHK(ensure_scratch(c, SCR_IO_A, L * 64, &d));
+    HIPCHK(hipMemcpyAsync(d, leaves, L * 64, hipMemcpyHostToDevice, c->stream));
+    return sh_dev_merkle_commit(c, (const uint8_t*)d, L, root);
+}
+int32_t sh_dev_hash_leaves(sh_ctx* c, const uint64_t* d_elems, size_t L, uint8_t* d_out) {
+    CTXCHK(c);
+    if (L == 0) return SH_OK;
+    if (!d_elems || !d_out) return sh_fail(SH_EINVAL, "sh_dev_hash_leaves: null pointer");
+    HIPCHK(launch_hash_leaves((const fp*)d_elems, (digest64*)d_out, L, c->stream));
+    return SH_OK;
+}
+int32_t sh_hash_leaves(sh_ctx* c, const uint64_t* elems, size_t L, uint8_t* out) {
+    CTXCHK(c);
+    if (L == 0) return SH_OK;
+    if (!elems || !out) return sh_fail(SH_EINVAL, "sh_hash_leaves: null pointer");
+    void *din, *dout;
+    SHCHK(ensure_scratch(c, SCR_IO_A, L * 16, &din));
+    SHCHK(ensure_scratch(c, SCR_IO_B, L * 64, &dout));
+    HIPCHK(hipMemcpyAsync(din, elems, L * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_hash_leaves((const fp*)din, (digest64*)dout, L, c->stream));
+    HIPCHK(hipMemcpyAsync(out, dout, L * 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SH_OK;
+}
+int32_t sh_dev_merkle_commit_elems(sh_ctx* c, const uint64_t* d_elems, size_t L, uint8_t root[64]) {
+    CTXCHK(c);
+    if (!d_elems || !root) return sh_fail(SH_EINVAL, "sh_dev_merkle_commit_elems: null pointer");
+    if (!is_pow2(L)) return sh_fail(SH_EINVAL, "sh_merkle_commit_elems: element count must be a power of two (merkle.rs:36)");
+    SHCHK(merkle_root_from_elems(c, (const fp*)d_elems, L));
+    return fetch_root(c, root);
+}
+int32_t sh_merkle_commit_elems(sh_ctx* c, const uint64_t* elems, size_t L, uint8_t root[64]) {
+    CTXCHK(c);
+    if (!elems || !root) return sh_fail(SH_EINVAL, "sh_merkle_commit_elems: null pointer");
+    if (!is_pow2(L)) return sh_fail(SH_EINVAL, "sh_merkle_commit_elems: element count must be a power of two (merkle.rs:36)");
+    void* d;
+    SHCHK(ensure_scratch(c, SCR_IO_A, L * 16, &d));
+    HIPCHK(hipMemcpyAsync(d, elems, L * 16, hipMemcpyHostToDevice, c->stream));
+    return sh_dev_merkle_commit_elems(c, (const uint64_t*)d, L, root);
+}
+// MerkleTree::open, merkle.rs:70-108.  All levels are built once on the GPU (level by level, K = 1) and the
+// log2(L) siblings are gathered from them, instead of the reference's per-call subtree re-commits.
+int32_t sh_merkle_open(sh_ctx* c, const uint8_t* leaves, size_t L, size_t index, uint8_t* path, size_t* path_len) {
+    CTXCHK(c);
+    if (!leaves || !path || !path_len) return sh_fail(SH_EINVAL, "sh_merkle_open: null pointer");
+    if (!is_pow2(L)) return sh_fail(SH_EINVAL, "sh_merkle_open: leaf count must be a power of two (merkle.rs:72)");
+    if (index >= L) return sh_fail(SH_EBOUNDS, "sh_merkle_open: index out of bounds (merkle.rs:75)");
+    if (L < 2) return sh_fail(SH_EBOUNDS, "sh_merkle_open: a one-leaf tree has no path (merkle.rs:104)");
+    const uint32_t depth = ilog2(L);
+    void* d;                                   // levels 0..depth-1 back to back: L + L/2 + ... + 2 digests
+    SHCHK(ensure_scratch(c, SCR_IO_A, 2 * L * 64, &d));
+    digest64* lvl = (digest64*)d;
+    HIPCHK(hipMemcpyAsync(lvl, leaves, L * 64, hipMemcpyHostToDevice, c->stream));
+    size_t n = L, idx = index;
+    for (uint32_t l = 0; l < depth; ++l) {
+        HIPCHK(hipMemcpyAsync(path + 64 * (size_t)l, lvl + (idx ^ 1), 64, hipMemcpyDeviceToHost, c->stream));
+        if (l + 1 < depth) HIPCHK(launch_node_subtree(lvl, lvl + n, n >> 1, 1, c->stream));
+        lvl += n; n >>= 1; idx >>= 1;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *path_len = depth;
+    return SH_OK;
+}
+
+int32_t sh_dev_fri_fold(sh_ctx* c, const uint64_t* d_cw, size_t L, const uint64_t alpha[2], const uint64_t offset[2],
+                        const uint64_t omega[2], uint64_t* d_out) {
+    CTXCHK(c);
+    if (!d_cw || !alpha || !offset || !omega || !d_out) return sh_fail(SH_EINVAL, "sh_dev_fri_fold: null pointer");
+    if (!is_pow2(L) || L < 2) return sh_fail(SH_EINVAL, "sh_fri_fold: L must be a power of two >= 2");
+    const fp a = fp_load_host(alpha), off = fp_load_host(offset), w = fp_load_host(omega);
+    if (!fp_is_canonical(a) || !fp_is_canonical(off) || !fp_is_canonical(w)) return sh_fail(SH_EINVAL, "sh_fri_fold: non-canonical scalar");
+    if (fp_is_zero(off) || fp_is_zero(w)) return sh_fail(SH_EDIVZERO, "Cannot divide by zero");      // alpha/(offset·omega^i), field.rs:102
+    const fp c0 = fp_mul(fp_mul(a, fp_inv(fp_make(2, 0, 0, 0))), fp_inv(off));
+    HIPCHK(launch_fri_fold((const fp*)d_cw, L, fp_to_mont(c0), fp_inv(w), (fp*)d_out, c->stream));
+    return SH_OK;
+}
+int32_t sh_fri_fold(sh_ctx* c, const uint64_t* cw, size_t L, const uint64_t alpha[2], const uint64_t offset[2],
+                    const uint64_t omega[2], uint64_t* out) {
+    CTXCHK(c);
+    if (!cw || !out) return sh_fail(SH_EINVAL, "sh_fri_fold: null pointer");
+    if (!is_pow2(L) || L < 2) return sh_fail(SH_EINVAL, "sh_fri_fold: L must be a power of two >= 2");
+    void *din, *dout;
+    SHCHK(ensure_scratch(c, SCR_IO_A, L * 16, &din));
+    SHCHK(ensure_scratch(c, SCR_IO_B, L * 8, &dout));
+    HIPCHK(hipMemcpyAsync(din, cw, L * 16, hipMemcpyHostToDevice, c->stream));
+    SHCHK(sh_dev_fri_fold(c, (const uint64_t*)din, L, alpha, offset, omega, (uint64_t*)dout));
+    HIPCHK(hipMemcpyAsync(out, dout, L * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SH_OK;
+}
+
+uint32_t sh_fri_num_rounds(size_t N, uint32_t expansion, uint32_t num_colinearity_tests) {
+    uint32_t r = 0;
+    size_t len = N;
+    while (len > expansion && 4 * (size_t)num_colinearity_tests < len) { len /= 2; ++r; }
+    return r;
+}
+int32_t sh_dev_fri_commit(sh_ctx* c, const uint64_t* d_codeword, size_t N, const sh_fri_params* params, sh_transcript_cb cb, void* user,
+                          uint8_t* roots_out, uint64_t* last_codeword_out, size_t* last_len) {
+    return fri_commit_dev(c, (const fp*)d_codeword, N, params, cb, user, roots_out, last_codeword_out, last_len);
+}
+int32_t sh_fri_commit(sh_ctx* c, const uint64_t* codeword, size_t N, const sh_fri_params* params, sh_transcript_cb cb, void* user,
+                      uint8_t* roots_out, uint64_t* last_codeword_out, size_t* last_len) {
+    CTXCHK(c);
+    if (!codeword) return sh_fail(SH_EINVAL, "sh_fri_commit: null pointer");
+    if (!is_pow2(N) || ilog2(N) > SH_MAX_LOG_N) return sh_fail(SH_EINVAL, "sh_fri_commit: N must be a power of two <= 2^28");
+    void* d;
+    SHCHK(ensure_scratch(c, SCR_IO_C, N * 16, &d));
+    HIPCHK(hipMemcpyAsync(d, codeword, N * 16, hipMemcpyHostToDevice, c->stream));
+    return fri_commit_dev(c, (const fp*)d, N, params, cb, user, roots_out, last_codeword_out, last_len);
+}
+int32_t sh_dev_fri_commit_proofstream(sh_ctx* c, const uint64_t* d_codeword, size_t N, const sh_fri_params* params, sh_proofstream* ps,
+                                      uint8_t* roots_out, uint64_t* last_codeword_out, size_t* last_len) {
+    if (!ps) return sh_fail(SH_EINVAL, "sh_fri_commit_proofstream: null proof stream");
+    PsCbState st{ps};
+    SHCHK(fri_commit_dev(c, (const fp*)d_codeword, N, params, ps_callback, &st, roots_out, last_codeword_out, last_len));
+    return sh_proofstream_push_codeword(ps, last_codeword_out, *last_len);
+}
+int32_t sh_fri_commit_proofstream(sh_ctx* c, const uint64_t* codeword, size_t N, const sh_fri_params* params, sh_proofstream* ps,
+                                  uint8_t* roots_out, uint64_t* last_codeword_out, size_t* last_len) {
+    if (!ps) return sh_fail(SH_EINVAL, "sh_fri_commit_proofstream: null proof stream");
+    PsCbState st{ps};
+    SHCHK(sh_fri_commit(c, codeword, N, params, ps_callback, &st, roots_out, last_codeword_out, last_len));
+    return sh_proofstream_push_codeword(ps, last_codeword_out, *last_len);
+}
+
+// ------------------------------------------------------------------ host-only scalar helpers
+int32_t sh_sample_field(const uint8_t digest[32], uint64_t out[2]) {          // G3: big-endian integer mod p
+    if (!digest || !out) return sh_fail(SH_EINVAL, "sh_sample_field: null pointer");
+    uint64_t w[4] = {0, 0, 0, 0};                                            // w[0] most significant
+    for (int i = 0; i < 32; ++i) w[i / 8] = (w[i / 8] << 8) | digest[i];
+    const fp hi = fp_reduce_once(fp_from_u64x2(w[1], w[0])), lo = fp_reduce_once(fp_from_u64x2(w[3], w[2]));
+    fp_store_host(out, fp_add(mont_mul(hi, fp_mont_r2()), lo));             // hi·2^128 + lo (mod p)
+    return SH_OK;
+}
+int32_t sh_root_of_unity(uint32_t log_n, uint64_t out[2]) {                  // G1
+    if (!out) return sh_fail(SH_EINVAL, "sh_root_of_unity: null pointer");
+    if (log_n > 119) return sh_fail(SH_EINVAL, "sh_root_of_unity: the field has no root of unity of order > 2^119");
+    fp_store_host(out, host_root_of_unity(log_n));
+    return SH_OK;
+}
+int32_t sh_generator(uint64_t out[2]) {
+    if (!out) return sh_fail(SH_EINVAL, "sh_generator: null pointer");
+    fp_store_host(out, host_generator());
+    return SH_OK;
+}
+int32_t sh_fp_scalar(int32_t op, const uint64_t a[2], const uint64_t b[2], uint64_t out[2]) {
+    if (!a || !b || !out) return sh_fail(SH_EINVAL, "sh_fp_scalar: null pointer");
+    fp x = fp_load_host(a), y = fp_load_host(b), r;
+    if (!fp_is_canonical(x) || (op != 4 && !fp_is_canonical(y))) return sh_fail(SH_EINVAL, "sh_fp_scalar: non-canonical operand");
+    switch (op) {
+    case 0: r = fp_add(x, y); break;                                         // field.rs:57-68
+    case 1: r = fp_sub(x, y); break;                                         // field.rs:70-82
+    case 2: r = fp_mul(x, y); break;                                         // field.rs:84-95
+    case 3:                                                                  // field.rs:97-114
+        if (fp_is_zero(y)) return sh_fail(SH_EDIVZERO, "Cannot divide by zero");
+        r = fp_mul(x, fp_inv(y));
+        break;
+    case 4: r = fp_pow(x, fp_to_u128(y)); break;                             // true modpow
+    default: return sh_fail(SH_EINVAL, "sh_fp_scalar: unknown op");
+    }
+    fp_store_host(out, r);
+    return SH_OK;
+}
+
+}  // extern "C"

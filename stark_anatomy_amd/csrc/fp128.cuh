@@ -1,0 +1,128 @@
+// fp128.cuh — prime-field arithmetic for p = 1 + 407·2^119 (reference: src/field/types/field.rs:15)
+// on the CDNA4 integer VALU.  Replaces the reference's I320 widen / schoolbook / Knuth-division /
+// ext-Euclid path (src/field/types/base.rs:94-151, src/field/utils.rs:3-18) wholesale; results
+// are the same canonical residues in [0,p) that field.rs:57-114 returns.
+//
+// Representation: 4 x u32 little-endian limbs (16 B, one dwordx4 per element).  Data in HBM is
+// always the CANONICAL value.  Multiplication is Montgomery (R = 2^128): mont_mul(a,b) = a·b·R^-1.
+// Twiddles/constants are kept in Montgomery form (w·R), so data(canonical) × twiddle(Montgomery)
+// -> canonical with a single mont_mul and no conversions.
+//
+// Reduction exploits the shape of p:  p ≡ 1 (mod 2^119)  =>  p^-1 ≡ 1 − 407·2^119 (mod 2^128),
+// so M = T_lo·p^-1 mod 2^128 only touches the top 9 bits of T_lo, and M·p = M + (407·M)·2^119
+// costs four 32x32 multiplies by the constant 407.  Subtractive form:
+//     a·b·R^-1 = T_hi − floor(M·p / 2^128)   (+p if negative)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FP_HD __host__ __device__ __forceinline__
+
+struct alignas(16) fp {
+    uint32_t w[4];
+};
+
+// p limbs
+#define FP_P0 0x00000001u
+#define FP_P3 0xcb800000u
+// R mod p = 2^128 - p
+#define FP_R0 0xffffffffu
+#define FP_R3 0x347fffffu
+
+FP_HD fp fp_make(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { fp r; r.w[0] = a; r.w[1] = b; r.w[2] = c; r.w[3] = d; return r; }
+FP_HD fp fp_zero() { return fp_make(0, 0, 0, 0); }
+FP_HD fp fp_one() { return fp_make(1, 0, 0, 0); }
+FP_HD fp fp_prime() { return fp_make(FP_P0, 0, 0, FP_P3); }
+FP_HD fp fp_mont_one() { return fp_make(FP_R0, 0xffffffffu, 0xffffffffu, FP_R3); }                         // R mod p
+FP_HD fp fp_mont_r2() { return fp_make(0x0e778236u, 0x5bd53a7fu, 0x1a6aedc2u, 0xaaf4ad9au); }             // R^2 mod p
+FP_HD fp fp_from_u64x2(uint64_t lo, uint64_t hi) { return fp_make((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)); }
+FP_HD uint64_t fp_lo64(fp a) { return (uint64_t)a.w[0] | ((uint64_t)a.w[1] << 32); }
+FP_HD uint64_t fp_hi64(fp a) { return (uint64_t)a.w[2] | ((uint64_t)a.w[3] << 32); }
+FP_HD bool fp_is_zero(fp a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) == 0; }
+FP_HD bool fp_eq(fp a, fp b) { return a.w[0] == b.w[0] && a.w[1] == b.w[1] && a.w[2] == b.w[2] && a.w[3] == b.w[3]; }
+
+typedef unsigned __int128 fp_u128;
+FP_HD fp_u128 fp_to_u128(fp a) { return ((fp_u128)fp_hi64(a) << 64) | fp_lo64(a); }
+FP_HD fp fp_from_u128(fp_u128 v) { return fp_from_u64x2((uint64_t)v, (uint64_t)(v >> 64)); }
+FP_HD fp_u128 fp_prime_u128() { return ((fp_u128)0xcb80000000000000ULL << 64) | 1u; }
+
+// (a + b) mod p for canonical a, b           [field.rs:57-68]
+FP_HD fp fp_add(fp a, fp b) {
+    fp_u128 x = fp_to_u128(a), y = fp_to_u128(b), s = x + y, d = s - fp_prime_u128();
+    bool ge = (s < x) | (s >= fp_prime_u128());
+    return fp_from_u128(ge ? d : s);
+}
+// (a - b) mod p for canonical a, b           [field.rs:70-82]
+FP_HD fp fp_sub(fp a, fp b) {
+    fp_u128 x = fp_to_u128(a), y = fp_to_u128(b), d = x - y;
+    return fp_from_u128(x < y ? d + fp_prime_u128() : d);
+}
+FP_HD fp fp_neg(fp a) { return fp_is_zero(a) ? a : fp_from_u128(fp_prime_u128() - fp_to_u128(a)); }
+// a / 2 mod p
+FP_HD fp fp_half(fp a) {
+    fp_u128 x = fp_to_u128(a);
+    if (x & 1) {                       // (x + p) / 2 ; x + p may carry past 2^128
+        fp_u128 s = x + fp_prime_u128();
+        fp_u128 c = (s < x) ? ((fp_u128)1 << 127) : 0;
+        return fp_from_u128((s >> 1) | c);
+    }
+    return fp_from_u128(x >> 1);
+}
+// reduce an arbitrary 128-bit value into [0,p)  [field.rs:30-35 `new`]; p > 2^127 so one subtraction
+FP_HD fp fp_reduce_once(fp a) {
+    fp_u128 x = fp_to_u128(a);
+    return fp_from_u128(x >= fp_prime_u128() ? x - fp_prime_u128() : x);
+}
+
+// mont_mul(a, b) = a·b·2^-128 mod p, canonical result.  Requires b < p; a may be any 128-bit value.
+// [replaces field.rs:84-95 -> base.rs:94-151 + ruint div]
+FP_HD fp mont_mul(fp a, fp b) {
+    uint32_t t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint64_t x = (uint64_t)a.w[j] * b.w[i] + t[i + j] + c;   // <= 2^64-1, no overflow
+            t[i + j] = (uint32_t)x;
+            c = x >> 32;
+        }
+        t[i + 4] = (uint32_t)c;
+    }
+    // M = T_lo · p^-1 mod 2^128 = T_lo − ((T_lo·407 mod 2^9) << 119)
+    uint32_t k9 = (t[0] * 407u) & 511u;
+    uint32_t m0 = t[0], m1 = t[1], m2 = t[2], m3 = t[3] - (k9 << 23);
+    // U = 407·M (137 bits)
+    uint64_t x0 = (uint64_t)m0 * 407u;
+    uint64_t x1 = (uint64_t)m1 * 407u + (x0 >> 32);
+    uint64_t x2 = (uint64_t)m2 * 407u + (x1 >> 32);
+    uint64_t x3 = (uint64_t)m3 * 407u + (x2 >> 32);
+    uint32_t u0 = (uint32_t)x0, u1 = (uint32_t)x1, u2 = (uint32_t)x2, u3 = (uint32_t)x3, u4 = (uint32_t)(x3 >> 32);
+    // floor(M·p / 2^128) = (U >> 9) + carry,  carry = [ (M >> 119) + (U & 511) >= 512 ]
+    uint32_t cy = ((m3 >> 23) + (u0 & 511u)) >> 9;
+    uint32_t q0 = (u0 >> 9) | (u1 << 23), q1 = (u1 >> 9) | (u2 << 23), q2 = (u2 >> 9) | (u3 << 23), q3 = (u3 >> 9) | (u4 << 23);
+    fp_u128 q = (((fp_u128)(((uint64_t)q3 << 32) | q2)) << 64) | (((uint64_t)q1 << 32) | q0);
+    q += cy;
+    fp_u128 th = (((fp_u128)(((uint64_t)t[7] << 32) | t[6])) << 64) | (((uint64_t)t[5] << 32) | t[4]);
+    fp_u128 r = th - q;
+    if (th < q) r += fp_prime_u128();
+    return fp_from_u128(r);
+}
+FP_HD fp fp_to_mont(fp a) { return mont_mul(a, fp_mont_r2()); }             // a·R
+FP_HD fp fp_from_mont(fp a) { return mont_mul(a, fp_one()); }               // a·R^-1
+// canonical × canonical -> canonical (two Montgomery multiplies)          [field.rs:84-95]
+FP_HD fp fp_mul(fp a, fp b) { return mont_mul(mont_mul(a, b), fp_mont_r2()); }
+// a^e for canonical a (true modular exponentiation; SURVEY.md Q1 — NOT field.rs:37-46's wrapping pow)
+FP_HD fp fp_pow(fp a, fp_u128 e) {
+    fp base = fp_to_mont(a), acc = fp_mont_one();
+    while (e) {
+        if (e & 1) acc = mont_mul(acc, base);
+        base = mont_mul(base, base);
+        e >>= 1;
+    }
+    return fp_from_mont(acc);
+}
+// a^-1 = a^(p-2): the unique inverse in [1,p) that field.rs:109-110 derives from ext-Euclid. a != 0.
+FP_HD fp fp_inv(fp a) { return fp_pow(a, fp_prime_u128() - 2); }

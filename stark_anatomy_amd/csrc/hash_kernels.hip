@@ -1,0 +1,210 @@
+// hash_kernels.hip — Blake2b-512 leaf hashing, Merkle construction and the fused FRI round on gfx950.
+//
+// Replaces MerkleTree::commit's strictly sequential loop (merkle.rs:48-60: one thread, L-1
+// compressions) and the per-element field divisions of a naive split-and-fold (field.rs:97-114).
+//
+// Structure.  Blake2b is 64-bit add/xor/rotate work on a 32-bit VALU (~2.3k VALU ops per
+// compression) — the commit is integer-ALU bound, not HBM bound.  What matters is
+// keeping every lane busy: a level-by-level tree inside a wave/workgroup idles half the lanes per
+// level.  So each LANE owns a whole 2^K-leaf subtree and walks it depth-first with a K-deep stack
+// of pending left siblings held in registers: 2^(K+1)-1 compressions per lane, no LDS, no
+// barriers, no idle lanes.  Each kernel contains exactly one unrolled leaf compression and one
+// unrolled node compression (the loops around them are rolled) so the instruction stream stays
+// inside the instruction cache.  Only the last <= 512 nodes are reduced level by level in LDS by
+// a single workgroup (k_merkle_tail).
+#include "kernels.h"
+
+#define SUBTREE_KMAX 4
+
+// Depth-first reduction of 2^K items produced by `leaf(i)` (i ascending) to one digest.
+// Every loop bound and stack index is wave-uniform.
+template <class LeafFn>
+__device__ __forceinline__ digest64 subtree_reduce(uint32_t K, LeafFn leaf) {
+    digest64 lv0, lv1, lv2, lv3, cur;
+    const uint32_t count = 1u << K;
+#pragma unroll 1
+    for (uint32_t i = 0; i < count; ++i) {
+        cur = leaf(i);
+        uint32_t j = 0;
+#pragma unroll 1
+        for (; (i >> j) & 1u; ++j) {
+            digest64 left;
+            switch (j) {
+            case 0: left = lv0; break;
+            case 1: left = lv1; break;
+            case 2: left = lv2; break;
+            default: left = lv3; break;
+            }
+            cur = b2b_node(left, cur);                   // merkle.rs:52-54: H(left || right)
+        }
+        switch (j) {
+        case 0: lv0 = cur; break;
+        case 1: lv1 = cur; break;
+        case 2: lv2 = cur; break;
+        default: lv3 = cur; break;
+        }
+    }
+    return cur;
+}
+
+__device__ __forceinline__ void store_digest(digest64* __restrict__ p, const digest64& d) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(d.h);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ digest64 load_digest(const digest64* __restrict__ p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    digest64 d;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint4 v = q[i];
+        d.h[2 * i] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        d.h[2 * i + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+    return d;
+}
+
+__global__ __launch_bounds__(256) void k_hash_leaves(const fp* __restrict__ elems, digest64* __restrict__ out, size_t L) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += stride) {
+        fp e = elems[i];
+        store_digest(out + i, b2b_leaf(fp_lo64(e), fp_hi64(e)));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_leaf_subtree(const fp* __restrict__ elems, digest64* __restrict__ out, size_t n_out, uint32_t K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const fp* base = elems + (i << K);
+    digest64 d = subtree_reduce(K, [&](uint32_t q) {
+        fp e = base[q];
+        return b2b_leaf(fp_lo64(e), fp_hi64(e));
+    });
+    store_digest(out + i, d);
+}
+
+__global__ __launch_bounds__(256) void k_node_subtree(const digest64* __restrict__ in, digest64* __restrict__ out, size_t n_out, uint32_t K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const digest64* base = in + (i << K);
+    digest64 d = subtree_reduce(K, [&](uint32_t q) { return load_digest(base + q); });
+    store_digest(out + i, d);
+}
+
+// Top of the tree: n_in <= 512 nodes -> root, built level by level in LDS by one workgroup.
+__global__ __launch_bounds__(256) void k_merkle_tail(const digest64* __restrict__ in, digest64* __restrict__ root, uint32_t n_in) {
+    __shared__ digest64 sm[MERKLE_TAIL_MAX];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < n_in; i += blockDim.x) sm[i] = load_digest(in + i);
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t n = n_in; n > 1; n >>= 1) {
+        const uint32_t half = n >> 1;
+        digest64 r;
+        const bool act = tid < half;
+        if (act) r = b2b_node(sm[2 * tid], sm[2 * tid + 1]);
+        __syncthreads();
+        if (act) sm[tid] = r;
+        __syncthreads();
+    }
+    if (tid == 0) store_digest(root, sm[0]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FRI split-and-fold:
+//   out[i] = 2^-1·((1 + a/(off·w^i))·x + (1 − a/(off·w^i))·y),  x = cw[i], y = cw[L/2+i]
+//          = (x + y)/2 + (a·2^-1·off^-1)·w^-i·(x − y)            (same canonical residue)
+// One Montgomery multiply per output plus the twiddle; no per-element division (field.rs:97-114).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ fp fold_one(fp x, fp y, fp t_mont) {     // t_mont = c0·w^-i in Montgomery form
+    return fp_add(fp_half(fp_add(x, y)), mont_mul(fp_sub(x, y), t_mont));
+}
+
+#define FOLD_PER_THREAD 4
+__global__ __launch_bounds__(256) void k_fri_fold(const fp* __restrict__ cw, size_t half, fp c0_mont, fp omega_inv,
+                                                  fp* __restrict__ out) {
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * FOLD_PER_THREAD;
+    if (i0 >= half) return;
+    // t = c0 · omega_inv^i0 (Montgomery form), by square-and-multiply; then stepped by omega_inv
+    fp step = fp_to_mont(omega_inv), base = step, t = c0_mont;
+    for (size_t e = i0; e; e >>= 1) {
+        if (e & 1) t = mont_mul(t, base);
+        base = mont_mul(base, base);
+    }
+#pragma unroll 1
+    for (int q = 0; q < FOLD_PER_THREAD && i0 + q < half; ++q) {
+        out[i0 + q] = fold_one(cw[i0 + q], cw[half + i0 + q], t);
+        t = mont_mul(t, step);
+    }
+}
+
+__device__ __forceinline__ fp load_tw(const fp* __restrict__ tw, uint32_t log_n, size_t e) {
+    // tw = [lo: w^i, i < min(n,4096) | hi: w^(4096·i)], Montgomery form
+    fp lo = tw[e & ((1u << NTT_TW_LO_BITS) - 1)];
+    if (log_n <= NTT_TW_LO_BITS) return lo;
+    fp hi = tw[(1u << NTT_TW_LO_BITS) + (e >> NTT_TW_LO_BITS)];
+    return mont_mul(lo, hi);
+}
+
+// Fused FRI round: fold, write the folded codeword, and hash it into 2^K-leaf subtree digests.
+__global__ __launch_bounds__(256) void k_fold_leaf_subtree(const fp* __restrict__ cw, size_t half, fp c0_mont,
+                                                           const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
+                                                           fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out, uint32_t K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const size_t j0 = i << K;
+    digest64 d = subtree_reduce(K, [&](uint32_t q) {
+        const size_t j = j0 + q;
+        fp t = mont_mul(load_tw(tw_inv, log_n_table, j << tw_shift), c0_mont);
+        fp v = fold_one(cw[j], cw[half + j], t);
+        out[j] = v;
+        return b2b_leaf(fp_lo64(v), fp_hi64(v));
+    });
+    store_digest(digests + i, d);
+}
+
+// ---------------------------------------------------------------------------------------------
+static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+hipError_t launch_hash_leaves(const fp* elems, digest64* out, size_t L, hipStream_t s) {
+    if (!L) return hipSuccess;
+    size_t blocks = (L + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_hash_leaves, dim3((unsigned)blocks), dim3(256), 0, s, elems, out, L);
+    return hipGetLastError();
+}
+hipError_t launch_leaf_subtree(const fp* elems, digest64* out, size_t n_out, uint32_t K, hipStream_t s) {
+    if (!n_out) return hipSuccess;
+    if (K > SUBTREE_KMAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_leaf_subtree, dim3(grid_for(n_out, 256)), dim3(256), 0, s, elems, out, n_out, K);
+    return hipGetLastError();
+}
+hipError_t launch_node_subtree(const digest64* in, digest64* out, size_t n_out, uint32_t K, hipStream_t s) {
+    if (!n_out) return hipSuccess;
+    if (K < 1 || K > SUBTREE_KMAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_node_subtree, dim3(grid_for(n_out, 256)), dim3(256), 0, s, in, out, n_out, K);
+    return hipGetLastError();
+}
+hipError_t launch_merkle_tail(const digest64* in, digest64* root, size_t n_in, hipStream_t s) {
+    if (n_in == 0 || n_in > MERKLE_TAIL_MAX || (n_in & (n_in - 1))) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_merkle_tail, dim3(1), dim3(256), 0, s, in, root, (uint32_t)n_in);
+    return hipGetLastError();
+}
+hipError_t launch_fri_fold(const fp* cw, size_t L, fp c0_mont, fp omega_inv, fp* out, hipStream_t s) {
+    const size_t half = L / 2;
+    if (!half) return hipErrorInvalidValue;
+    const size_t threads = (half + FOLD_PER_THREAD - 1) / FOLD_PER_THREAD;
+    hipLaunchKernelGGL(k_fri_fold, dim3(grid_for(threads, 256)), dim3(256), 0, s, cw, half, c0_mont, omega_inv, out);
+    return hipGetLastError();
+}
+hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, fp c0_mont, const fp* tw_inv, uint32_t log_n_table,
+                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s) {
+    const size_t half = L / 2;
+    if (!half || K > SUBTREE_KMAX || (half >> K) == 0) return hipErrorInvalidValue;
+    const size_t n_out = half >> K;
+    hipLaunchKernelGGL(k_fold_leaf_subtree, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, half, c0_mont, tw_inv,
+                       log_n_table, tw_shift, out, digests, n_out, K);
+    return hipGetLastError();
+}

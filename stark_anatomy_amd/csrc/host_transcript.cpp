@@ -1,0 +1,345 @@
+// host_transcript.cpp — host side of the hot path: SHA-256, general-length BLAKE2b-512, Merkle path
+// verification and the ProofStream transcript (proof_stream.rs:17-69).  Per Fiat-Shamir round this is
+// ~300 bytes of JSON and a few SHA-256 blocks, so it stays on the host exactly where the reference
+// has it; what matters is that the BYTES are identical to serde_json's compact output.
+//
+// This is product code (part of libstark_hip.so).  It shares nothing with oracle/.
+#include <stdint.h>
+#include <string.h>
+#include <new>
+#include <string>
+#include <vector>
+#include "../../include/stark_hip.h"
+#include "host_internal.h"
+
+// ------------------------------------------------------------------ SHA-256 (FIPS 180-4)
+namespace {
+const uint32_t K256[64] = {
+    0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u,
+    0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu,
+    0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u,
+    0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u,
+    0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u, 0x1e376c08u,
+    0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
+    0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+inline uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+struct Sha256 {
+    uint32_t st[8];
+    uint8_t buf[64];
+    size_t fill = 0;
+    uint64_t total = 0;
+    Sha256() {
+        static const uint32_t init[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+        memcpy(st, init, sizeof st);
+    }
+    void block(const uint8_t* p) {
+        uint32_t w[64];
+        for (int i = 0; i < 16; ++i) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+        for (int i = 16; i < 64; ++i) {
+            uint32_t a = w[i - 15], b = w[i - 2];
+            w[i] = w[i - 16] + (ror(a, 7) ^ ror(a, 18) ^ (a >> 3)) + w[i - 7] + (ror(b, 17) ^ ror(b, 19) ^ (b >> 10));
+        }
+        uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+        for (int i = 0; i < 64; ++i) {
+            uint32_t t1 = h + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i];
+            uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+    }
+    void update(const uint8_t* p, size_t n) {
+        total += n;
+        if (fill) {
+            size_t take = 64 - fill < n ? 64 - fill : n;
+            memcpy(buf + fill, p, take); fill += take; p += take; n -= take;
+            if (fill == 64) { block(buf); fill = 0; }
+        }
+        while (n >= 64) { block(p); p += 64; n -= 64; }
+        if (n) { memcpy(buf, p, n); fill = n; }
+    }
+    void finish(uint8_t out[32]) {
+        uint64_t bits = total * 8;
+        uint8_t pad[72] = {0x80};
+        size_t padlen = (fill < 56) ? 56 - fill : 120 - fill;
+        uint8_t len[8];
+        for (int i = 0; i < 8; ++i) len[i] = (uint8_t)(bits >> (56 - 8 * i));
+        update(pad, padlen);
+        update(len, 8);
+        for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16); out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i]; }
+    }
+};
+
+// ------------------------------------------------------------------ BLAKE2b-512 (RFC 7693), any length, unkeyed
+const uint64_t BIV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                         0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+const uint8_t BSIG[10][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+inline uint64_t ror64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+void b2_compress(uint64_t h[8], const uint8_t blk[128], uint64_t t, bool last) {
+    uint64_t v[16], m[16];
+    for (int i = 0; i < 8; ++i) { v[i] = h[i]; v[i + 8] = BIV[i]; }
+    v[12] ^= t;
+    if (last) v[14] = ~v[14];
+    for (int i = 0; i < 16; ++i) { uint64_t w; memcpy(&w, blk + 8 * i, 8); m[i] = w; }   // little-endian host
+    auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+        v[a] += v[b] + x; v[d] = ror64(v[d] ^ v[a], 32); v[c] += v[d]; v[b] = ror64(v[b] ^ v[c], 24);
+        v[a] += v[b] + y; v[d] = ror64(v[d] ^ v[a], 16); v[c] += v[d]; v[b] = ror64(v[b] ^ v[c], 63);
+    };
+    for (int r = 0; r < 12; ++r) {
+        const uint8_t* s = BSIG[r % 10];
+        G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+        G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+        G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+        G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+    }
+    for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+}
+}  // namespace
+
+void host_sha256(const uint8_t* in, size_t len, uint8_t out[32]) {
+    Sha256 s;
+    s.update(in, len);
+    s.finish(out);
+}
+void host_blake2b512(const uint8_t* in, size_t len, uint8_t out[64]) {
+    uint64_t h[8];
+    memcpy(h, BIV, sizeof h);
+    h[0] ^= 0x01010040ULL;
+    uint64_t t = 0;
+    uint8_t blk[128];
+    while (len > 128) { t += 128; b2_compress(h, in, t, false); in += 128; len -= 128; }
+    memset(blk, 0, sizeof blk);
+    if (len) memcpy(blk, in, len);
+    t += len;
+    b2_compress(h, blk, t, true);
+    memcpy(out, h, 64);
+}
+
+// ------------------------------------------------------------------ ProofStream (proof_stream.rs:17-69)
+struct sh_proofstream {
+    std::vector<std::string> items;   // compact-JSON fragment per item
+    size_t read_index = 0;
+};
+
+namespace {
+void append_u64_dec(std::string& s, uint64_t v) {
+    char tmp[24]; int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) s.push_back(tmp[--n]);
+}
+void append_u128_dec(std::string& s, unsigned __int128 v) {      // serde_json writes u128 as a bare decimal integer
+    char tmp[40]; int n = 0;
+    do { tmp[n++] = (char)('0' + (int)(v % 10)); v /= 10; } while (v);
+    while (n) s.push_back(tmp[--n]);
+}
+std::string serialize_items(const std::vector<std::string>& items, size_t count) {   // serialize_inner, proof_stream.rs:67-69
+    size_t need = 2;
+    for (size_t i = 0; i < count; ++i) need += items[i].size() + 1;
+    std::string out;
+    out.reserve(need);
+    out.push_back('[');
+    for (size_t i = 0; i < count; ++i) { if (i) out.push_back(','); out += items[i]; }
+    out.push_back(']');
+    return out;
+}
+
+// Minimal JSON value scanner: validates one value starting at p and appends its compact form to `out`.
+struct JsonScan {
+    const uint8_t* p; const uint8_t* end; int depth = 0;
+    void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; }
+    bool lit(const char* s, std::string& out) { size_t n = strlen(s); if ((size_t)(end - p) < n || memcmp(p, s, n)) return false; out.append(s, n); p += n; return true; }
+    bool str(std::string& out) {
+        if (p >= end || *p != '"') return false;
+        out.push_back('"'); ++p;
+        while (p < end) {
+            uint8_t c = *p++;
+            if (c < 0x20) return false;
+            out.push_back((char)c);
+            if (c == '\\') { if (p >= end) return false; out.push_back((char)*p++); }
+            else if (c == '"') return true;
+        }
+        return false;
+    }
+    bool num(std::string& out) {
+        const uint8_t* s = p;
+        if (p < end && *p == '-') ++p;
+        if (p >= end || *p < '0' || *p > '9') return false;
+        if (*p == '0') ++p; else while (p < end && *p >= '0' && *p <= '9') ++p;
+        if (p < end && *p == '.') { ++p; if (p >= end || *p < '0' || *p > '9') return false; while (p < end && *p >= '0' && *p <= '9') ++p; }
+        if (p < end && (*p == 'e' || *p == 'E')) { ++p; if (p < end && (*p == '+' || *p == '-')) ++p; if (p >= end || *p < '0' || *p > '9') return false; while (p < end && *p >= '0' && *p <= '9') ++p; }
+        out.append((const char*)s, (size_t)(p - s));
+        return true;
+    }
+    bool value(std::string& out) {
+        if (++depth > 128) return false;                      // serde_json's recursion limit
+        ws();
+        if (p >= end) return false;
+        bool ok;
+        if (*p == '{') {
+            out.push_back('{'); ++p; ws();
+            if (p < end && *p == '}') { ++p; out.push_back('}'); ok = true; }
+            else {
+                ok = false;
+                for (;;) {
+                    ws(); if (!str(out)) break;
+                    ws(); if (p >= end || *p != ':') break; ++p; out.push_back(':');
+                    if (!value(out)) break;
+                    ws(); if (p >= end) break;
+                    if (*p == ',') { ++p; out.push_back(','); continue; }
+                    if (*p == '}') { ++p; out.push_back('}'); ok = true; }
+                    break;
+                }
+            }
+        } else if (*p == '[') {
+            out.push_back('['); ++p; ws();
+            if (p < end && *p == ']') { ++p; out.push_back(']'); ok = true; }
+            else {
+                ok = false;
+                for (;;) {
+                    if (!value(out)) break;
+                    ws(); if (p >= end) break;
+                    if (*p == ',') { ++p; out.push_back(','); continue; }
+                    if (*p == ']') { ++p; out.push_back(']'); ok = true; }
+                    break;
+                }
+            }
+        } else if (*p == '"') ok = str(out);
+        else if (*p == 't') ok = lit("true", out);
+        else if (*p == 'f') ok = lit("false", out);
+        else if (*p == 'n') ok = lit("null", out);
+        else ok = num(out);
+        --depth;
+        return ok;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int32_t sh_sha256(const uint8_t* in, size_t len, uint8_t out[32]) {
+    if ((!in && len) || !out) return sh_fail(SH_EINVAL, "sh_sha256: null pointer");
+    host_sha256(in, len, out);
+    return SH_OK;
+}
+int32_t sh_blake2b512(const uint8_t* in, size_t len, uint8_t out[64]) {
+    if ((!in && len) || !out) return sh_fail(SH_EINVAL, "sh_blake2b512: null pointer");
+    host_blake2b512(in, len, out);
+    return SH_OK;
+}
+// MerkleTree::verify / is_leaf_in_tree, merkle.rs:110-154
+int32_t sh_merkle_verify(const uint8_t root[64], const uint8_t leaf[64], const uint8_t* path, size_t path_len, size_t index, int32_t* ok) {
+    if (!root || !leaf || !ok || (!path && path_len)) return sh_fail(SH_EINVAL, "sh_merkle_verify: null pointer");
+    if (path_len == 0) return sh_fail(SH_EINVAL, "sh_merkle_verify: empty path (merkle.rs:126)");
+    if (path_len < 8 * sizeof(size_t) && index >= ((size_t)1 << path_len)) return sh_fail(SH_EBOUNDS, "sh_merkle_verify: index >= 2^path_len (merkle.rs:122)");
+    uint8_t cur[64], buf[128];
+    memcpy(cur, leaf, 64);
+    for (size_t i = 0; i < path_len; ++i) {
+        if ((index & 1) == 0) { memcpy(buf, cur, 64); memcpy(buf + 64, path + 64 * i, 64); }   // merkle.rs:133-134
+        else { memcpy(buf, path + 64 * i, 64); memcpy(buf + 64, cur, 64); }                   // merkle.rs:135-136
+        host_blake2b512(buf, 128, cur);
+        index >>= 1;
+    }
+    *ok = memcmp(cur, root, 64) == 0;
+    return SH_OK;
+}
+
+int32_t sh_proofstream_new(sh_proofstream** out) {
+    if (!out) return sh_fail(SH_EINVAL, "sh_proofstream_new: null out");
+    *out = new (std::nothrow) sh_proofstream();
+    return *out ? SH_OK : sh_fail(SH_ENOMEM, "sh_proofstream_new: out of memory");
+}
+int32_t sh_proofstream_free(sh_proofstream* ps) { delete ps; return SH_OK; }
+int32_t sh_proofstream_push_json(sh_proofstream* ps, const uint8_t* json, size_t len) {       // proof_stream.rs:25-27
+    if (!ps || (!json && len)) return sh_fail(SH_EINVAL, "sh_proofstream_push_json: null pointer");
+    ps->items.emplace_back((const char*)json, len);
+    return SH_OK;
+}
+int32_t sh_proofstream_push_merkle_root(sh_proofstream* ps, const uint8_t root[64]) {         // merkle.rs:9-13 shape
+    if (!ps || !root) return sh_fail(SH_EINVAL, "sh_proofstream_push_merkle_root: null pointer");
+    std::string s = "{\"MerkleRoot\":{\"inner\":[";
+    for (int i = 0; i < 64; ++i) { if (i) s.push_back(','); append_u64_dec(s, root[i]); }
+    s += "]}}";
+    ps->items.push_back(std::move(s));
+    return SH_OK;
+}
+int32_t sh_proofstream_push_codeword(sh_proofstream* ps, const uint64_t* elems, size_t n) {
+    if (!ps || (!elems && n)) return sh_fail(SH_EINVAL, "sh_proofstream_push_codeword: null pointer");
+    std::string s = "{\"Codeword\":[";
+    s.reserve(16 + n * 40);
+    for (size_t i = 0; i < n; ++i) {
+        if (i) s.push_back(',');
+        append_u128_dec(s, ((unsigned __int128)elems[2 * i + 1] << 64) | elems[2 * i]);
+    }
+    s += "]}";
+    ps->items.push_back(std::move(s));
+    return SH_OK;
+}
+int32_t sh_proofstream_len(sh_proofstream* ps, size_t* n_items, size_t* read_index) {
+    if (!ps) return sh_fail(SH_EINVAL, "sh_proofstream_len: null pointer");
+    if (n_items) *n_items = ps->items.size();
+    if (read_index) *read_index = ps->read_index;
+    return SH_OK;
+}
+int32_t sh_proofstream_pull(sh_proofstream* ps, const uint8_t** json, size_t* len) {          // proof_stream.rs:29-36
+    if (!ps || !json || !len) return sh_fail(SH_EINVAL, "sh_proofstream_pull: null pointer");
+    if (ps->read_index >= ps->items.size()) return sh_fail(SH_EBOUNDS, "Read index is out of bounds");
+    const std::string& s = ps->items[ps->read_index++];
+    *json = (const uint8_t*)s.data();
+    *len = s.size();
+    return SH_OK;
+}
+int32_t sh_proofstream_serialize(sh_proofstream* ps, uint8_t* out, size_t cap, size_t* needed) {   // proof_stream.rs:38-40
+    if (!ps || !needed) return sh_fail(SH_EINVAL, "sh_proofstream_serialize: null pointer");
+    std::string s = serialize_items(ps->items, ps->items.size());
+    *needed = s.size();
+    if (out && cap >= s.size()) memcpy(out, s.data(), s.size());
+    else if (out) return sh_fail(SH_EINVAL, "sh_proofstream_serialize: buffer too small");
+    return SH_OK;
+}
+int32_t sh_proofstream_deserialize(const uint8_t* bytes, size_t len, sh_proofstream** out) {       // proof_stream.rs:42-49
+    if (!bytes || !out) return sh_fail(SH_EINVAL, "sh_proofstream_deserialize: null pointer");
+    JsonScan sc{bytes, bytes + len};
+    sc.ws();
+    if (sc.p >= sc.end || *sc.p != '[') return sh_fail(SH_EPARSE, "Serialization error: expected a JSON array");
+    ++sc.p;
+    sh_proofstream* ps = new (std::nothrow) sh_proofstream();
+    if (!ps) return sh_fail(SH_ENOMEM, "sh_proofstream_deserialize: out of memory");
+    sc.ws();
+    bool ok = false;
+    if (sc.p < sc.end && *sc.p == ']') { ++sc.p; ok = true; }
+    else {
+        for (;;) {
+            std::string item;
+            if (!sc.value(item)) break;
+            ps->items.push_back(std::move(item));
+            sc.ws();
+            if (sc.p >= sc.end) break;
+            if (*sc.p == ',') { ++sc.p; continue; }
+            if (*sc.p == ']') { ++sc.p; ok = true; }
+            break;
+        }
+    }
+    sc.ws();
+    if (!ok || sc.p != sc.end) { delete ps; return sh_fail(SH_EPARSE, "Serialization error: malformed JSON"); }
+    *out = ps;
+    return SH_OK;
+}
+int32_t sh_proofstream_prover_fiat_shamir(sh_proofstream* ps, uint8_t out[32]) {                   // proof_stream.rs:51-56
+    if (!ps || !out) return sh_fail(SH_EINVAL, "sh_proofstream_prover_fiat_shamir: null pointer");
+    std::string s = serialize_items(ps->items, ps->items.size());
+    host_sha256((const uint8_t*)s.data(), s.size(), out);
+    return SH_OK;
+}
+int32_t sh_proofstream_verifier_fiat_shamir(sh_proofstream* ps, uint8_t out[32]) {                 // proof_stream.rs:58-64
+    if (!ps || !out) return sh_fail(SH_EINVAL, "sh_proofstream_verifier_fiat_shamir: null pointer");
+    std::string s = serialize_items(ps->items, ps->read_index);
+    host_sha256((const uint8_t*)s.data(), s.size(), out);
+    return SH_OK;
+}
+
+}  // extern "C"

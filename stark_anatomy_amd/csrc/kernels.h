@@ -1,0 +1,47 @@
+// kernels.h — host-callable launchers of the HIP kernels (internal; the public ABI is include/stark_hip.h).
+// All launchers enqueue on `s` and return the hipError_t of the launch; they never synchronise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "blake2b.cuh"
+#include "fp128.cuh"
+
+// ---- field_kernels.hip ----
+enum { FPOP_ADD = 0, FPOP_SUB = 1, FPOP_MUL = 2, FPOP_DIV = 3, FPOP_INV = 4, FPOP_NEW = 5 };
+// out[i] = a[i] op b[i]; *d_flag is set to 1 if a zero divisor is met (FPOP_DIV / FPOP_INV).
+hipError_t launch_fp_binop(int op, const fp* a, const fp* b, fp* out, size_t n, uint32_t* d_flag, hipStream_t s);
+
+// ---- ntt_kernels.hip ----
+#define NTT_MAX_PASSES 4
+#define NTT_TW_LO_BITS 12                    // lo table: w^i, i < 4096 ; hi table: w^(4096 i)
+struct NttPlan {
+    uint32_t log_n;
+    uint32_t num_passes;
+    uint32_t bits[NTT_MAX_PASSES];           // radix bits per pass, sum == log_n; bits[0] is the most significant input digit
+};
+void ntt_make_plan(uint32_t log_n, NttPlan* plan);
+// tw = [lo (min(n,4096)) | hi (max(n >> 12, 1))] Montgomery-form powers of the (inverse) n-th root.
+// scale_mont: Montgomery-form factor applied at the final store (R mod p == 1, or n^-1·R for the inverse).
+// `data` is transformed in place; `scratch` holds n elements.
+hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, hipStream_t s);
+// out[j] = j < n ? coeffs[j]·offset^j : 0   for j < N  (coset pre-scale + zero pad, G7)
+hipError_t launch_coset_scale_pad(const fp* coeffs, size_t n, fp offset, fp* out, size_t N, hipStream_t s);
+
+// ---- hash_kernels.hip ----
+// out[i] = Blake2b512(le16(elems[i]))
+hipError_t launch_hash_leaves(const fp* elems, digest64* out, size_t L, hipStream_t s);
+// out[i] = root of the 2^K-leaf subtree over leafhash(elems[i·2^K .. (i+1)·2^K)), 0 <= K <= 4
+hipError_t launch_leaf_subtree(const fp* elems, digest64* out, size_t n_out, uint32_t K, hipStream_t s);
+// out[i] = root of the 2^K-node subtree over in[i·2^K .. (i+1)·2^K), 1 <= K <= 4
+hipError_t launch_node_subtree(const digest64* in, digest64* out, size_t n_out, uint32_t K, hipStream_t s);
+// single workgroup: n_in (power of two, <= 512) digests -> 1 root, levels built in LDS
+#define MERKLE_TAIL_MAX 512
+hipError_t launch_merkle_tail(const digest64* in, digest64* root, size_t n_in, hipStream_t s);
+
+// ---- fri_kernels.hip ----
+// generic split-and-fold (any omega): out[i] = (a+b)/2 + c0·omega^-i·(a-b),  c0 = alpha/(2·offset)
+hipError_t launch_fri_fold(const fp* cw, size_t L, fp c0_mont, fp omega_inv, fp* out, hipStream_t s);
+// fused round: fold cw (length L) into out (length L/2) with twiddles w_N^-(i << tw_shift) from the
+// inverse table of the top-level domain, and emit the 2^K-leaf subtree digests of the folded codeword.
+hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, fp c0_mont, const fp* tw_inv, uint32_t log_n_table,
+                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s);

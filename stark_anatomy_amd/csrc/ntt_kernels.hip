@@ -1,0 +1,216 @@
+// ntt_kernels.hip — radix-2^b multi-pass NTT / INTT and coset pre-scale on gfx950.
+// Not in the reference; built from field.rs Add/Sub/Mul semantics only, natural order in and out:
+//   X[k] = sum_j x[j]·w^(jk),  w = g^(2^119/n).
+//
+// Decomposition (generalised four-step, no separate transposes).  log_n = b_0 + … + b_{P-1}, each
+// b_i <= 8.  Index digits j = (j_0 … j_{P-1}), j_0 most significant; k = k_0 + R_0·k_1 + ….
+//   pass p < P-1 : inside every contiguous sub-block of m_p = n/(R_0…R_{p-1}) elements, R_p-point DFTs
+//                  over the stride-(m_p/R_p) digit for C contiguous columns at a time, then the
+//                  inter-pass twiddle w_{m_p}^(col·k_p); in place (each tile owns its addresses).
+//   final pass   : R_{P-1}-point DFTs over the contiguous digit, for C adjacent values of k_0, and the
+//                  digit-reversing scatter to natural order — reads C rows of R contiguous elements,
+//                  writes R rows of C contiguous elements (the transpose happens inside LDS).
+// A tile (R rows × C columns, <= 4096 elements = 64 KiB) lives in LDS for all log2(R) butterfly
+// levels; HBM sees one coalesced read and one coalesced write of the array per pass.
+// Butterflies are decimation-in-frequency, so rows come out bit-reversed and the reversal is
+// absorbed into the store address.  Twiddles come from a two-level table of Montgomery-form powers
+// (4096 + n/4096 entries, L2-resident): w^e = lo[e & 4095]·hi[e >> 12].
+#include "kernels.h"
+
+struct NttPassParams {
+    const fp* in;
+    fp* out;
+    const fp* tw;                 // [lo | hi]
+    uint32_t log_n, log_m, log_r, log_c;
+    uint32_t is_final, log_r0;    // final pass: bits of digit 0
+    uint32_t num_mid, mid_bits[NTT_MAX_PASSES];   // final pass: middle digit widths, most significant first
+    uint32_t apply_scale;
+    fp scale;                     // Montgomery form
+};
+
+__device__ __forceinline__ fp ntt_load_tw(const fp* __restrict__ tw, uint32_t log_n, size_t e) {
+    fp lo = tw[e & ((1u << NTT_TW_LO_BITS) - 1)];
+    if (log_n <= NTT_TW_LO_BITS) return lo;
+    fp hi = tw[(1u << NTT_TW_LO_BITS) + (e >> NTT_TW_LO_BITS)];
+    return mont_mul(lo, hi);
+}
+
+__global__ __launch_bounds__(256) void k_ntt_pass(NttPassParams p) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    fp* x = reinterpret_cast<fp*>(lds_raw);
+    const uint32_t R = 1u << p.log_r, C = 1u << p.log_c, T = R * C;
+    const uint32_t rs = (p.is_final && p.log_c) ? C + 1 : C;      // padded row stride: transposed fill stays conflict-free
+    fp* twr = x + (size_t)R * rs;                                 // w_R^e, e < R/2 (Montgomery form)
+    const uint32_t tid = threadIdx.x;
+    const size_t tile = blockIdx.x;
+
+    for (uint32_t e = tid; e < (R >> 1); e += blockDim.x) twr[e] = ntt_load_tw(p.tw, p.log_n, (size_t)e << (p.log_n - p.log_r));
+
+    size_t base, row_stride_in;
+    uint32_t colbase = 0;
+    if (!p.is_final) {
+        const uint32_t log_mp = p.log_m - p.log_r;                // sub-sub-block (column count), log2
+        const size_t chunks = (size_t)1 << (log_mp - p.log_c);
+        const size_t block = tile / chunks, chunk = tile % chunks;
+        colbase = (uint32_t)(chunk << p.log_c);
+        base = (block << p.log_m) + colbase;
+        row_stride_in = (size_t)1 << log_mp;
+        for (uint32_t idx = tid; idx < T; idx += blockDim.x) {
+            const uint32_t r = idx >> p.log_c, c = idx & (C - 1);
+            x[r * rs + c] = p.in[base + (size_t)r * row_stride_in + c];
+        }
+    } else {
+        const size_t chunks = (size_t)1 << (p.log_r0 - p.log_c);  // chunks of digit-0 values
+        const size_t mid = tile / chunks, chunk = tile % chunks;
+        colbase = (uint32_t)(chunk << p.log_c);
+        base = mid << p.log_r;
+        row_stride_in = (size_t)1 << (p.log_n - p.log_r0);        // stride of digit 0 in the in-place layout
+        for (uint32_t idx = tid; idx < T; idx += blockDim.x) {
+            const uint32_t c = idx >> p.log_r, r = idx & (R - 1); // contiguous digit fastest: coalesced rows
+            x[r * rs + c] = p.in[(size_t)(colbase + c) * row_stride_in + base + r];
+        }
+    }
+    __syncthreads();
+
+    // log2(R) decimation-in-frequency levels in LDS
+#pragma unroll 1
+    for (int lh = (int)p.log_r - 1; lh >= 0; --lh) {
+        const uint32_t half = 1u << lh;
+        for (uint32_t b = tid; b < (T >> 1); b += blockDim.x) {
+            const uint32_t c = b & (C - 1), q = b >> p.log_c;
+            const uint32_t j = q & (half - 1), i = ((q >> lh) << (lh + 1)) | j;
+            fp u = x[i * rs + c], v = x[(i + half) * rs + c];
+            x[i * rs + c] = fp_add(u, v);
+            fp d = fp_sub(u, v);
+            if (lh) d = mont_mul(d, twr[j << (p.log_r - 1 - lh)]);
+            x[(i + half) * rs + c] = d;
+        }
+        __syncthreads();
+    }
+
+    if (!p.is_final) {
+        const uint32_t tw_shift = p.log_n - p.log_m;              // w_m = w_n^(n/m)
+        for (uint32_t idx = tid; idx < T; idx += blockDim.x) {
+            const uint32_t r = idx >> p.log_c, c = idx & (C - 1);
+            const uint32_t k = __brev(r) >> (32 - p.log_r);
+            fp v = x[r * rs + c];
+            const size_t e = ((size_t)(colbase + c) * k) << tw_shift;
+            v = mont_mul(v, ntt_load_tw(p.tw, p.log_n, e));
+            p.out[base + (size_t)k * row_stride_in + c] = v;
+        }
+    } else {
+        // out index = k_0 + R_0·(midrev + M·k_last)
+        const size_t chunks = (size_t)1 << (p.log_r0 - p.log_c);
+        size_t mid = tile / chunks, midrev = 0;
+        uint32_t log_M = 0;
+        for (int q = (int)p.num_mid - 1; q >= 0; --q) { log_M += p.mid_bits[q]; }
+        {
+            uint32_t sh = 0;                                       // digits are stored most-significant-first in `mid`
+            size_t rem = mid;
+            for (int q = (int)p.num_mid - 1; q >= 0; --q) {        // peel least significant (= last middle digit) first
+                const size_t dq = rem & (((size_t)1 << p.mid_bits[q]) - 1);
+                rem >>= p.mid_bits[q];
+                sh += p.mid_bits[q];
+                midrev |= dq << (log_M - sh);
+            }
+        }
+        for (uint32_t idx = tid; idx < T; idx += blockDim.x) {
+            const uint32_t r = idx >> p.log_c, c = idx & (C - 1);
+            const uint32_t k = p.log_r ? (__brev(r) >> (32 - p.log_r)) : 0;
+            fp v = x[r * rs + c];
+            if (p.apply_scale) v = mont_mul(v, p.scale);
+            p.out[(size_t)(colbase + c) + ((((size_t)k << log_M) + midrev) << p.log_r0)] = v;
+        }
+    }
+}
+
+void ntt_make_plan(uint32_t log_n, NttPlan* plan) {
+    plan->log_n = log_n;
+    uint32_t P = log_n <= 8 ? 1 : (log_n + 7) / 8;
+    plan->num_passes = P;
+    for (uint32_t i = 0; i < NTT_MAX_PASSES; ++i) plan->bits[i] = 0;
+    uint32_t rem = log_n;
+    for (uint32_t i = 0; i < P; ++i) {                 // spread evenly, larger digits first
+        uint32_t b = (rem + (P - i) - 1) / (P - i);
+        plan->bits[i] = b;
+        rem -= b;
+    }
+}
+
+static size_t pass_lds_bytes(uint32_t log_r, uint32_t log_c, bool is_final) {
+    const size_t R = (size_t)1 << log_r, C = (size_t)1 << log_c;
+    const size_t rs = (is_final && log_c) ? C + 1 : C;
+    return (R * rs + (R >> 1) + 1) * sizeof(fp);
+}
+
+hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const uint32_t P = plan.num_passes, log_n = plan.log_n;
+    uint32_t consumed = 0;
+    for (uint32_t pi = 0; pi < P; ++pi) {
+        NttPassParams p{};
+        p.tw = tw;
+        p.log_n = log_n;
+        p.log_r = plan.bits[pi];
+        p.apply_scale = 0;
+        p.scale = scale_mont;
+        const bool is_final = (pi == P - 1);
+        p.is_final = is_final;
+        if (!is_final) {
+            p.log_m = log_n - consumed;
+            const uint32_t log_mp = p.log_m - p.log_r;
+            p.log_c = (12 - p.log_r) < log_mp ? (12 - p.log_r) : log_mp;
+            p.in = data;                                               // non-final passes work in place on `data` ...
+            p.out = (pi + 2 == P) ? scratch : data;                    // ... except the last one, which lands in scratch
+        } else {
+            p.log_r0 = (P >= 2) ? plan.bits[0] : 0;
+            p.log_c = (12 - p.log_r) < p.log_r0 ? (12 - p.log_r) : p.log_r0;
+            p.num_mid = (P >= 2) ? P - 2 : 0;
+            for (uint32_t q = 0; q < p.num_mid; ++q) p.mid_bits[q] = plan.bits[1 + q];
+            p.apply_scale = apply_scale ? 1 : 0;
+            p.in = (P >= 2) ? scratch : data;
+            p.out = data;
+        }
+        const size_t tiles = ((size_t)1 << log_n) >> (p.log_r + p.log_c);
+        const size_t lds = pass_lds_bytes(p.log_r, p.log_c, is_final);
+        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(256), lds, s, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        consumed += p.log_r;
+    }
+    return hipSuccess;
+}
+
+// out[j] = j < n ? coeffs[j]·offset^j : 0 ; each lane owns 4 consecutive j: one square-and-multiply
+// for offset^j0, then three steps.
+#define SCALE_PER_THREAD 4
+__global__ __launch_bounds__(256) void k_coset_scale_pad(const fp* __restrict__ coeffs, size_t n, fp offset, fp* __restrict__ out, size_t N) {
+    const size_t j0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * SCALE_PER_THREAD;
+    if (j0 >= N) return;
+    if (j0 >= n) {
+#pragma unroll
+        for (int q = 0; q < SCALE_PER_THREAD; ++q) if (j0 + q < N) out[j0 + q] = fp_zero();
+        return;
+    }
+    fp step = fp_to_mont(offset), base = step, t = fp_mont_one();
+    for (size_t e = j0; e; e >>= 1) {
+        if (e & 1) t = mont_mul(t, base);
+        base = mont_mul(base, base);
+    }
+#pragma unroll 1
+    for (int q = 0; q < SCALE_PER_THREAD && j0 + q < N; ++q) {
+        out[j0 + q] = (j0 + q < n) ? mont_mul(coeffs[j0 + q], t) : fp_zero();
+        t = mont_mul(t, step);
+    }
+}
+
+hipError_t launch_coset_scale_pad(const fp* coeffs, size_t n, fp offset, fp* out, size_t N, hipStream_t s) {
+    const size_t threads = (N + SCALE_PER_THREAD - 1) / SCALE_PER_THREAD;
+    hipLaunchKernelGGL(k_coset_scale_pad, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, coeffs, n, offset, out, N);
+    return hipGetLastError();
+}

@@ -1,0 +1,182 @@
+"""
+CPU-side checks of the product library (no GPU needed, no compute kernels run):
+  - libstark_hip.so loads and exports every symbol include/stark_hip.h declares;
+  - compute entry points fail loudly (SH_EHIP) without a device — there is no CPU fallback;
+  - the host-side pieces of the path (ProofStream bytes, SHA-256, Blake2b, Merkle verify, sampling,
+    roots of unity, scalar field ops) match the reference's KATs, the golden vectors and the oracle.
+"""
+import ctypes as C
+import json
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import stark_anatomy_amd as sa
+from oracle import coracle as co
+from oracle import pyoracle as po
+from stark_anatomy_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = po.P
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "stark_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(sh_[a-z0-9_]+)\s*\(", hdr)) - {"sh_transcript_cb"})
+    assert len(declared) > 50
+    raw = C.CDLL(_lib.SO_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in stark_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared, "ctypes prototypes and header disagree"
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(sa.StarkHipError) as e:
+        sa.Context(0)
+    assert e.value.code == _lib.SH_EHIP and "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "stark_anatomy_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".cuh", ".h")):
+                text = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "stark_oracle.h" not in text and "liboracle" not in text, f
+
+
+def test_scalar_field_ops_reference_kats(golden):
+    k = golden("ref_kat.json")["field"]
+    F = sa.FieldElement
+    assert F(2).pow(F(160)).value() == int(k["pow"]["expected"])                       # field.rs:140-151
+    assert (F(P - 10) + F(12)).value() == 2                                            # field.rs:153-166
+    assert (sa.ZERO - F(12)).value() == P - 12                                         # field.rs:168-180
+    a, b = F(int(k["mul"]["a"])), F(int(k["mul"]["b"]))
+    assert (a * b).value() == int(k["mul"]["expected"])                                # field.rs:182-194
+    assert (a / b).value() == int(k["div"]["expected"])                                # field.rs:196-208
+    for m in k["inv_minus"]["k"]:                                                      # field.rs:210-220
+        x = F(P - m)
+        assert ((F(1) / x) * x).value() == 1
+    with pytest.raises(ZeroDivisionError):                                             # field.rs:101-103
+        F(1) / F(0)
+    assert F(P + 5).value() == 5 and F(0).is_zero() and not F(1).is_zero()
+
+
+def test_scalar_field_ops_vs_golden_table_and_oracle(golden):
+    t = golden("field_ops.json")
+    F = sa.FieldElement
+    for r in t["rows"]:
+        a, b = F(int(r["a"])), F(int(r["b"]))
+        assert (a + b).value() == int(r["add"]) and (a - b).value() == int(r["sub"]) and (a * b).value() == int(r["mul"])
+        if r["div"] is not None:
+            assert (a / b).value() == int(r["div"])
+    rnd = random.Random(5)
+    for _ in range(500):
+        x, y = rnd.randrange(P), rnd.randrange(1, P)
+        assert (F(x) * F(y)).value() == co.fp_mul(x, y) and (F(x) / F(y)).value() == co.fp_div(x, y)
+        assert F(x).pow(y % 1000).value() == pow(x, y % 1000, P)
+
+
+def test_roots_of_unity_and_sampling(golden):
+    t = golden("ntt_vectors.json")
+    assert sa.generator().value() == int(t["generator"])
+    for k, v in t["roots_of_unity"].items():
+        assert sa.root_of_unity(int(k)).value() == int(v)
+    for v in golden("sample_vectors.json"):
+        assert sa.sample(bytes.fromhex(v["digest"])).value() == int(v["alpha"])
+    rnd = random.Random(2)
+    for _ in range(200):
+        d = bytes(rnd.randrange(256) for _ in range(32))
+        assert sa.sample(d).value() == co.sample(d) == int.from_bytes(d, "big") % P
+
+
+def _h(fn, data, n):
+    out = np.zeros(n, dtype=np.uint8)
+    assert fn(bytes(data), len(data), out.ctypes.data_as(_lib.u8p)) == 0
+    return out.tobytes()
+
+
+def test_host_hashes(golden):
+    for v in golden("blake2b_vectors.json"):
+        assert _h(_lib.lib.sh_blake2b512, bytes.fromhex(v["msg"]), 64).hex() == v["digest"]
+    for v in golden("sha256_vectors.json"):
+        assert _h(_lib.lib.sh_sha256, bytes.fromhex(v["msg"]), 32).hex() == v["digest"]
+    rnd = random.Random(9)
+    for n in list(range(0, 140)) + [255, 256, 257, 1000]:
+        m = bytes(rnd.randrange(256) for _ in range(n))
+        assert _h(_lib.lib.sh_blake2b512, m, 64) == co.blake2b512(m)
+        assert _h(_lib.lib.sh_sha256, m, 32) == co.sha256(m)
+
+
+def test_proof_stream_reference_kats(golden):
+    k = golden("ref_kat.json")["proof_stream"]
+    ps = sa.ProofStream()
+    for js in k["items_json"]:
+        ps.push(json.loads(js))                                                        # TestStruct {a, b}
+    assert list(ps.serialize()) == k["serialized"]                                     # proof_stream.rs:90-110
+    assert list(ps.prover_fiat_shamir()) == k["prover_fiat_shamir"]                    # proof_stream.rs:166-193
+    ps2 = sa.ProofStream.deserialize(ps.serialize())                                   # proof_stream.rs:112-129
+    assert ps2 == ps
+    for _ in range(k["verifier_pulls"]):
+        ps.pull()
+    assert list(ps.verifier_fiat_shamir()) == k["verifier_fiat_shamir"]                # proof_stream.rs:195-225
+    assert ps.pull() == {"a": 4, "b": 5}
+    with pytest.raises(sa.OutOfBoundsReadIndexError):                                  # proof_stream.rs:30-32
+        ps.pull()
+    psc = sa.ProofStream()
+    for js in k["complex_items_json"]:
+        psc.push(json.loads(js))
+    back = sa.ProofStream.deserialize(psc.serialize())                                 # proof_stream.rs:131-164
+    assert back == psc and back.pull() == json.loads(k["complex_items_json"][0])
+    assert sa.ProofStream.deserialize(b" [ {\"a\" : 1, \"b\":2} ,\n{\"a\":2,\"b\":3}]").serialize() == b'[{"a":1,"b":2},{"a":2,"b":3}]'
+    for bad in (b"", b"[", b"[1,]", b"{\"a\":1}", b"[1] x", b"[{\"a\":}]", b"[\"abc]"):
+        with pytest.raises(sa.SerializationError):                                     # proof_stream.rs:43
+            sa.ProofStream.deserialize(bad)
+    assert sa.ProofStream().serialize() == b"[]"
+
+
+def test_proof_items_match_oracle_bytes(golden):
+    e = golden("fri_c1.json")
+    ps, ops, pps = sa.ProofStream(item_from_json=None), co.ProofStream(), po.ProofStream()
+    for r in e["roots"]:
+        ps.push(sa.ProofItem.MerkleRoot(bytes.fromhex(r))); ops.push_root(bytes.fromhex(r)); pps.push(po.item_root(bytes.fromhex(r)))
+    last = [int(v) for v in e["last_codeword"]]
+    ps.push(sa.ProofItem.Codeword(last)); ops.push_codeword(co.to_arr(last)); pps.push(po.item_codeword(last))
+    assert ps.serialize() == ops.serialize() == pps.serialize() == e["stream"].encode()
+    assert ps.prover_fiat_shamir().hex() == e["final_fiat_shamir"]
+    back = sa.ProofStream.deserialize(ps.serialize(), item_from_json=sa.ProofItem.from_json)
+    assert back.pull() == sa.ProofItem.MerkleRoot(bytes.fromhex(e["roots"][0]))
+    big = [0, 1, P - 1, 2**64, 2**127 + 12345]                                          # u128 values print as bare decimals
+    ps3 = sa.ProofStream(); ps3.push(sa.ProofItem.Codeword(big))
+    assert ps3.serialize() == ('[{"Codeword":[' + ",".join(str(v) for v in big) + "]}]").encode()
+
+
+def test_merkle_verify_host_matches_oracle():
+    rnd = random.Random(4)
+    leaves = [bytes(rnd.randrange(256) for _ in range(64)) for _ in range(64)]
+    root = co.merkle_commit(leaves)
+    for i in (0, 1, 31, 63):
+        path = co.merkle_open(leaves, i)
+        mh = [sa.MerkleHash(h) for h in path]
+        assert sa.MerkleTree.is_leaf_in_tree(sa.MerkleHash(root), sa.MerkleHash(leaves[i]), mh, i)
+        assert not sa.MerkleTree.is_leaf_in_tree(sa.MerkleHash(root), sa.MerkleHash(leaves[i]), mh, i ^ 1)
+        assert not sa.MerkleTree.is_leaf_in_tree(sa.MerkleHash(root), sa.MerkleHash(leaves[i ^ 5]), mh, i)
+    with pytest.raises(AssertionError):                                                # merkle.rs:126
+        sa.MerkleTree.is_leaf_in_tree(sa.MerkleHash(root), sa.MerkleHash(leaves[0]), [], 0)
+    with pytest.raises(AssertionError):                                                # merkle.rs:122
+        sa.MerkleTree.is_leaf_in_tree(sa.MerkleHash(root), sa.MerkleHash(leaves[0]), [sa.MerkleHash(leaves[1])], 2)
+
+
+def test_num_rounds():
+    for N in (1, 2, 64, 128, 1024, 1 << 14, 1 << 20, 1 << 24):
+        for exp, t in ((4, 17), (4, 1), (1, 0), (8, 40)):
+            assert _lib.lib.sh_fri_num_rounds(N, exp, t) == co.fri_num_rounds(N, exp, t) == po.fri_num_rounds(N, exp, t)
+    assert _lib.lib.sh_fri_num_rounds(1024, 4, 17) == 4 and _lib.lib.sh_fri_num_rounds(1 << 20, 4, 17) == 14

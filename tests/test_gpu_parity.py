@@ -1,0 +1,350 @@
+"""
+GPU parity tests: every result of the HIP path, obtained through the C ABI (ctypes ->
+libstark_hip.so), must be BIT-EXACT with the CPU oracle on the same seeded inputs, with the committed
+golden vectors, and — at sizes the oracle cannot reach in seconds — satisfy size-independent
+properties (round trips, linearity, subtree composition).  Integer / byte work: tolerance is zero.
+"""
+import ctypes as C
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import stark_anatomy_amd as sa  # noqa: E402
+from oracle import coracle as co  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+from stark_anatomy_amd import _lib  # noqa: E402
+
+P, G = po.P, po.G
+EDGE = [0, 1, 2, P - 1, P - 2, 2**64 - 1, 2**64, 2**127, (1 << 128) % P, 2**64 - 3, 2**64 - 2, 2**32, 2**96 + 5, (P + 1) // 2, G]
+
+
+def digest(arr):
+    return hashlib.sha256(np.ascontiguousarray(arr, dtype="<u8").tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sa.Context(0)
+    yield c
+    c.close()
+
+
+# ------------------------------------------------------------------ field
+def test_field_batch_edge_table(ctx, golden):
+    t = golden("field_ops.json")
+    a = sa.FieldVector([int(r["a"]) for r in t["rows"]], ctx); b = sa.FieldVector([int(r["b"]) for r in t["rows"]], ctx)
+    assert (a + b).to_ints() == [int(r["add"]) for r in t["rows"]]
+    assert (a - b).to_ints() == [int(r["sub"]) for r in t["rows"]]
+    assert (a * b).to_ints() == [int(r["mul"]) for r in t["rows"]]
+    nz = [i for i, r in enumerate(t["rows"]) if r["div"] is not None]
+    an = sa.FieldVector(a.data[nz], ctx); bn = sa.FieldVector(b.data[nz], ctx)
+    assert (an / bn).to_ints() == [int(t["rows"][i]["div"]) for i in nz]
+    with pytest.raises(ZeroDivisionError):                              # field.rs:101-103
+        a / b
+    with pytest.raises(ZeroDivisionError):
+        sa.FieldVector([1, 0, 3], ctx).inverse()
+
+
+def test_field_batch_reference_kats(ctx, golden):
+    k = golden("ref_kat.json")["field"]
+    a = sa.FieldVector([int(k["mul"]["a"])] + [1] * 11, ctx)
+    b = sa.FieldVector([int(k["mul"]["b"])] + [P - m for m in k["inv_minus"]["k"]], ctx)
+    assert (a * b).to_ints()[0] == int(k["mul"]["expected"])            # field.rs:182-194
+    q = a / b
+    assert q.to_ints()[0] == int(k["div"]["expected"])                  # field.rs:196-208
+    assert (q * b).to_ints()[1:] == [1] * 11                            # field.rs:210-220
+    assert (sa.FieldVector([P - 10, 0], ctx) + sa.FieldVector([12, 0], ctx)).to_ints() == [2, 0]
+    assert (sa.FieldVector([0], ctx) - sa.FieldVector([12], ctx)).to_ints() == [P - 12]
+
+
+def test_field_batch_random_1m(ctx):
+    n = 1 << 20
+    a = co.splitmix_elems(21, n); b = co.splitmix_elems(22, n)
+    rnd = random.Random(3)
+    for i in range(0, 4096):                                            # sprinkle edge values
+        a[rnd.randrange(n)] = co.to_arr([rnd.choice(EDGE)])[0]
+        b[rnd.randrange(n)] = co.to_arr([rnd.choice(EDGE)])[0]
+    va, vb = sa.FieldVector(a, ctx), sa.FieldVector(b, ctx)
+    for op, res in (("add", va + vb), ("sub", va - vb), ("mul", va * vb)):
+        assert (res.data == co.fp_batch(op, a, b)).all(), op
+    m = 1 << 12
+    bz = b[:m].copy(); bz[(bz == 0).all(axis=1)] = co.to_arr([7])[0]
+    assert ((sa.FieldVector(a[:m], ctx) / sa.FieldVector(bz, ctx)).data == co.fp_batch("div", a[:m], bz)).all()
+    assert (sa.FieldVector(bz, ctx).inverse().data == co.fp_batch("inv", bz)).all()
+    raw = np.frombuffer(np.random.default_rng(1).bytes(16 * 4096), dtype=np.uint64).reshape(-1, 2).copy()
+    raw[0] = [0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF]; raw[1] = co.to_arr([P])[0]; raw[2] = co.to_arr([P - 1])[0]
+    assert sa.FieldVector.new(raw, ctx).to_ints() == [v % P for v in co.to_ints(raw)]     # field.rs:30-35
+
+
+# ------------------------------------------------------------------ hashing / Merkle
+def test_hash_leaves_and_merkle_golden(ctx, golden):
+    for e in golden("merkle_roots.json"):
+        L = e["L"]
+        elems = co.to_arr(list(range(L)))
+        leaves = sa.hash_leaves(elems, ctx)
+        assert (leaves == co.hash_leaves(elems)).all()
+        tree = sa.MerkleTree.commit(leaves, ctx)
+        assert tree.root.as_bytes().hex() == e["root"]
+        assert sa.commit_elems(elems, ctx).as_bytes().hex() == e["root"]
+        for i, path in e.get("open", {}).items():
+            assert [h.as_bytes().hex() for h in tree.open(int(i))] == path
+
+
+@pytest.mark.parametrize("log_l", [0, 1, 2, 3, 5, 9, 10, 11, 13, 16, 18])
+def test_merkle_commit_vs_oracle(ctx, log_l):
+    L = 1 << log_l
+    rng = np.random.default_rng(log_l)
+    leaves = np.frombuffer(rng.bytes(64 * L), dtype=np.uint8).reshape(L, 64).copy()
+    assert sa.MerkleTree.commit(leaves, ctx).root.as_bytes() == co.merkle_commit(leaves)
+    elems = co.splitmix_elems(50 + log_l, L)
+    assert sa.commit_elems(elems, ctx).as_bytes() == co.merkle_commit_elems(elems)
+
+
+def test_merkle_contract_violations(ctx):
+    leaves = np.zeros((3, 64), dtype=np.uint8)
+    root = np.zeros(64, dtype=np.uint8)
+    rc = _lib.lib.sh_merkle_commit(ctx.handle, leaves.ctypes.data_as(_lib.u8p), 3, root.ctypes.data_as(_lib.u8p))
+    assert rc == _lib.SH_EINVAL                                          # merkle.rs:36
+    rc = _lib.lib.sh_merkle_commit(ctx.handle, leaves.ctypes.data_as(_lib.u8p), 0, root.ctypes.data_as(_lib.u8p))
+    assert rc == _lib.SH_EINVAL
+    one = sa.MerkleTree.commit(leaves[:1], ctx)
+    assert one.root.as_bytes() == bytes(64)                              # merkle.rs:48,62 root == leaf
+    with pytest.raises(IndexError):                                      # merkle.rs:104 (Q5)
+        one.open(0)
+
+
+def test_merkle_reference_properties(ctx):                               # merkle.rs:178-282, N = 64
+    rnd = random.Random(8)
+    N = 64
+    rl = lambda: sa.MerkleHash(bytes(rnd.randrange(256) for _ in range(64)))
+    leaves = [rl() for _ in range(N)]
+    tree = sa.MerkleTree.commit(leaves, ctx)
+    fake = sa.MerkleTree.commit([rl()] * N, ctx)
+    oleaves = [h.as_bytes() for h in leaves]
+    assert tree.root.as_bytes() == co.merkle_commit(oleaves)
+    for i, leaf in enumerate(leaves):
+        path = tree.open(i)
+        assert [h.as_bytes() for h in path] == co.merkle_open(oleaves, i)
+        assert tree.verify(leaf, path, i)                                # verify_path_for_each_leaf
+        assert not tree.verify(rl(), path, i)                            # random_leaf_with_original_path
+        j = (i + 1 + rnd.randrange(N - 1)) % N
+        assert not tree.verify(leaves[j], path, i)                       # different_leaves_with_original_path
+        assert not tree.verify(leaf, path, j)                            # original_leaf_with_different_path_index
+        assert not fake.verify(leaf, path, i)                            # different_tree_original_leaves_and_paths
+        assert not sa.MerkleTree.is_leaf_in_tree(rl(), leaf, path, i)    # with_changed_root
+        if i % 8 == 0:
+            for t in range(len(path)):                                   # with_tampered_path
+                fp = list(path); fp[t] = rl()
+                assert not tree.verify(leaf, fp, i)
+
+
+def test_merkle_subtree_composition_large(ctx):
+    """2^22 leaves: root(all) == root(commit of the 4 quarter roots) — size-independent property."""
+    L = 1 << 22
+    elems = co.splitmix_elems(77, L)
+    whole = sa.commit_elems(elems, ctx)
+    q = L // 4
+    quarters = [sa.commit_elems(elems[i * q:(i + 1) * q], ctx) for i in range(4)]
+    assert sa.MerkleTree.commit(quarters, ctx).root == whole
+    assert quarters[3].as_bytes() == co.merkle_commit_elems(elems[3 * q:])
+
+
+# ------------------------------------------------------------------ NTT / LDE
+def test_ntt_golden(ctx, golden):
+    t = golden("ntt_vectors.json")
+    for e in t["ntt"]:
+        n = e["n"]
+        x = co.splitmix_elems(e["seed"], n) if "seed" in e else co.to_arr([j + 1 for j in range(n)])
+        y = sa.ntt(x, ctx=ctx)
+        if "out" in e:
+            assert co.to_ints(y) == [int(v) for v in e["out"]]
+        else:
+            assert digest(y) == e["out_sha256"]
+        assert (sa.intt(y, ctx=ctx) == x).all()
+
+
+@pytest.mark.parametrize("log_n", list(range(0, 21)))
+def test_ntt_vs_oracle_all_sizes(ctx, log_n):
+    x = co.splitmix_elems(300 + log_n, 1 << log_n)
+    y = sa.ntt(x, ctx=ctx)
+    assert (y == co.ntt(x)).all()
+    assert (sa.intt(x, ctx=ctx) == co.ntt(x, inverse=True)).all()
+    assert (sa.intt(y, ctx=ctx) == x).all()
+
+
+def test_ntt_edge_values(ctx):
+    for vals in ([0] * 512, [P - 1] * 512, [(P - 1) if i % 2 else 0 for i in range(1024)], EDGE + [0] * (16 - len(EDGE) % 16) if len(EDGE) % 16 else EDGE):
+        n = 1 << (len(vals) - 1).bit_length()
+        vals = list(vals) + [1] * (n - len(vals))
+        x = co.to_arr(vals)
+        assert (sa.ntt(x, ctx=ctx) == co.ntt(x)).all()
+
+
+def test_ntt_large_properties(ctx):
+    """2^24 points (the north-star size): INTT(NTT(x)) == x, linearity, and a naive spot check of
+    single outputs X[k] = sum_j x[j] w^(jk) for a sparse input."""
+    log_n = 24; n = 1 << log_n
+    x = co.splitmix_elems(5, n)
+    d = ctx.alloc(n * 16).upload(x)
+    sa.dev_ntt(ctx, d, log_n)
+    y = d.download(np.uint64, (n, 2))
+    sa.dev_ntt(ctx, d, log_n, inverse=True)
+    assert (d.download(np.uint64, (n, 2)) == x).all()
+    # sparse input: x = e_a + 3·e_b  ->  X[k] = w^(a k) + 3 w^(b k)
+    a, b = 12345, n - 7
+    s = np.zeros((n, 2), dtype=np.uint64); s[a, 0] = 1; s[b, 0] = 3
+    d.upload(s); sa.dev_ntt(ctx, d, log_n)
+    ys = d.download(np.uint64, (n, 2))
+    w = po.root_of_unity(log_n)
+    for k in (0, 1, 2, 4097, n // 2, n - 1, 7777777):
+        assert co.to_ints(ys[k:k + 1])[0] == (pow(w, a * k, P) + 3 * pow(w, b * k, P)) % P
+    # linearity: NTT(x + s) == NTT(x) + NTT(s)
+    xs = co.fp_batch("add", x, s)
+    d.upload(xs); sa.dev_ntt(ctx, d, log_n)
+    assert (d.download(np.uint64, (n, 2)) == co.fp_batch("add", y, ys)).all()
+    d.free()
+
+
+def test_lde_golden_and_oracle(ctx, golden):
+    for e in golden("lde_vectors.json"):
+        c = co.splitmix_elems(e["seed"], 1 << e["log_n"])
+        y = sa.coset_lde(c, e["log_expansion"], int(e["offset"]), ctx=ctx)
+        assert digest(y) == e["out_sha256"]
+    for log_n, le, off in ((0, 2, G), (3, 0, G), (5, 3, 12345), (10, 2, 1), (12, 2, P - 1)):
+        c = co.splitmix_elems(40 + log_n, 1 << log_n)
+        assert (sa.coset_lde(c, le, off, ctx=ctx) == co.coset_lde(c, le, off)).all()
+
+
+def test_c2_ntt_lde_merkle(ctx, golden):
+    """BASELINE config 2: single 2^16 NTT + coset LDE + Merkle commit, bit-exact vs CPU."""
+    e = golden("c2_lde_merkle.json")
+    c = co.splitmix_elems(e["seed"], 1 << e["log_n"])
+    assert digest(sa.ntt(c, ctx=ctx)) == e["ntt_sha256"]
+    y = sa.coset_lde(c, e["log_expansion"], int(e["offset"]), ctx=ctx)
+    assert digest(y) == e["lde_sha256"]
+    assert sa.commit_elems(y, ctx).as_bytes().hex() == e["merkle_root"]
+    assert (y == co.coset_lde(c, 2, G)).all()
+
+
+# ------------------------------------------------------------------ fold / FRI commit
+def test_fold_golden_and_oracle(ctx, golden):
+    e = golden("fold_vectors.json")
+    cw = co.splitmix_elems(e["seed"], e["L"])
+    out = sa.fold(cw, int(e["alpha"]), int(e["offset"]), int(e["omega"]), ctx=ctx)
+    assert co.to_ints(out) == [int(v) for v in e["out"]]
+    for log_l in (1, 2, 3, 7, 12, 16):
+        L = 1 << log_l
+        cw = co.splitmix_elems(60 + log_l, L)
+        alpha = co.to_ints(co.splitmix_elems(70 + log_l, 1))[0]
+        for off, om in ((G, po.root_of_unity(log_l)), (pow(G, 4, P), 987654321)):   # any omega is accepted
+            assert (sa.fold(cw, alpha, off, om, ctx=ctx) == co.fri_fold(cw, alpha, off, om)).all()
+    assert (sa.fold(cw, 0, G, po.root_of_unity(16), ctx=ctx) == co.fri_fold(cw, 0, G, po.root_of_unity(16))).all()
+    with pytest.raises(ZeroDivisionError):
+        sa.fold(cw, 5, 0, po.root_of_unity(16), ctx=ctx)
+
+
+@pytest.mark.parametrize("name", ["fri_c1.json", "fri_n4096.json", "fri_n16384.json"])
+def test_fri_commit_golden_transcripts(ctx, golden, name):
+    e = golden(name)
+    cw = co.splitmix_elems(e["seed"], e["N"])
+    fri = sa.Fri(int(e["offset"]), None, e["N"], e["expansion"], e["num_colinearity_tests"], ctx=ctx)
+    assert fri.num_rounds() == e["num_rounds"]
+    ps = sa.ProofStream()
+    roots, last = fri.commit(cw, ps)
+    assert [r.as_bytes().hex() for r in roots] == e["roots"]
+    assert last.shape[0] == e["last_len"] and digest(last) == e["last_codeword_sha256"]
+    ser = ps.serialize()
+    assert len(ser) == e["stream_len"] and hashlib.sha256(ser).hexdigest() == e["stream_sha256"]
+    assert ps.prover_fiat_shamir().hex() == e["final_fiat_shamir"]
+    if "stream" in e:
+        assert ser.decode() == e["stream"]
+    # device-resident codeword gives the same bytes
+    d = ctx.upload_elems(cw)
+    ps2 = sa.ProofStream()
+    fri.commit(d, ps2)
+    assert ps2.serialize() == ser
+    d.free()
+
+
+@pytest.mark.parametrize("log_n,seed", [(7, 1), (8, 2), (10, 3), (16, 4), (18, 6), (20, 3), (22, 8)])
+def test_fri_commit_vs_oracle(ctx, log_n, seed):
+    N = 1 << log_n
+    cw = co.splitmix_elems(seed, N)
+    fri = sa.Fri(G, None, N, 4, 17, ctx=ctx)
+    ps = sa.ProofStream()
+    roots, last = fri.commit(cw, ps)
+    oroots, oalphas, olast, ops = co.fri_commit(cw, 4, 17, G)
+    assert [r.as_bytes() for r in roots] == oroots
+    assert (last == olast).all()
+    assert ps.serialize() == ops.serialize()
+    # caller-owned transcript through the callback form gives the same alphas
+    seen = []
+    pps = po.ProofStream()
+
+    def cb(rnd, root, want):
+        pps.push(po.item_root(root))
+        if want:
+            a = po.sample(pps.prover_fiat_shamir()); seen.append(a); return a
+    r2, l2 = fri.commit_with_callback(cw, cb)
+    assert seen == oalphas and [r.as_bytes() for r in r2] == oroots and (l2 == olast).all()
+
+
+def test_fri_commit_other_parameters(ctx):
+    for N, exp, t, off in ((64, 4, 17, G), (256, 2, 3, pow(G, 3, P)), (1 << 12, 8, 40, G), (1 << 10, 1, 0, 5), (2, 1, 0, G), (1, 4, 17, G)):
+        cw = co.splitmix_elems(N + t, N)
+        ps = sa.ProofStream()
+        roots, last = sa.Fri(off, None, N, exp, t, ctx=ctx).commit(cw, ps)
+        oroots, _, olast, ops = co.fri_commit(cw, exp, t, off)
+        assert [r.as_bytes() for r in roots] == oroots and (last == olast).all() and ps.serialize() == ops.serialize()
+
+
+def test_fri_commit_2_24_properties(ctx):
+    """2^24-point commit (north-star size; the full oracle run takes ~1 min, so it is checked in pieces):
+    the round-0 root equals the oracle's Merkle root; the transcript replays on the host to the same bytes;
+    the fused fold+hash rounds agree with the standalone fold and Merkle entry points for every round; and
+    from round 12 (L = 4096) on, codewords and roots are compared with an oracle fold chain."""
+    log_n = 24; N = 1 << log_n
+    cw = co.splitmix_elems(5, N)
+    d = ctx.alloc(N * 16).upload(cw)
+    fri = sa.Fri(G, None, N, 4, 17, ctx=ctx)
+    R = fri.num_rounds(); assert R == 18
+    ps = sa.ProofStream()
+    roots, last = fri.commit(d, ps)
+    assert len(roots) == R and last.shape[0] == N >> (R - 1)
+    assert roots[0].as_bytes() == co.merkle_commit_elems(cw)
+    # transcript replay (host, pure Python): alphas derive from roots only
+    pps = po.ProofStream(); alphas = []
+    for r in range(R):
+        pps.push(po.item_root(roots[r].as_bytes()))
+        if r + 1 < R:
+            alphas.append(po.sample(pps.prover_fiat_shamir()))
+    pps.push(po.item_codeword(co.to_ints(last)))
+    assert pps.serialize() == ps.serialize()
+    # fold chain on the GPU with the public fold entry point, checked against the oracle from round 12 on
+    cur = d; L = N; off = G; om = po.root_of_unity(log_n)
+    host = None
+    for r in range(R - 1):
+        nxt = ctx.alloc(L * 8)
+        _lib.check(_lib.lib.sh_dev_fri_fold(ctx.handle, cur.ptr, L, sa.context._u64p(sa.context.scalar(alphas[r])),
+                                            sa.context._u64p(sa.context.scalar(off)), sa.context._u64p(sa.context.scalar(om)), nxt.ptr))
+        if host is not None:
+            host = co.fri_fold(host, alphas[r], off, om)
+        if cur is not d:
+            cur.free()
+        cur = nxt; L //= 2; off = off * off % P; om = om * om % P
+        if r + 1 == 12:
+            host = cur.download(np.uint64, (L, 2))
+        if host is not None:
+            got = cur.download(np.uint64, (L, 2))
+            assert (got == host).all()
+            assert co.merkle_commit_elems(host) == roots[r + 1].as_bytes()
+        else:
+            root = np.zeros(64, dtype=np.uint8)
+            _lib.check(_lib.lib.sh_dev_merkle_commit_elems(ctx.handle, cur.ptr, L, root.ctypes.data_as(_lib.u8p)))
+            assert root.tobytes() == roots[r + 1].as_bytes()
+    assert (cur.download(np.uint64, (L, 2)) == last).all()
+    cur.free(); d.free()
