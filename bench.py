@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""
+bench.py — FRI-commit throughput on MI355X (BASELINE.json metric: "FRI commit field-elems/s at 2^20 and
+2^24 domains, 1/2/4/8 GPU; NTT GB/s").
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is one full FRI commit (all fold rounds, all Merkle roots, host Fiat-Shamir transcript, last
+codeword back on the host) of one synthetic random codeword of N_dom = 2^--log-n elements that is already
+resident in HBM.  Each rank (one process per GPU) commits its own independent codeword — the path shards
+by whole commits with no data-path collective ("weak" scaling); `value` = all ranks' elements / max-over-
+ranks time.  Rank 0 prints ONE JSON line; the other figures the metric names (2^20 commit, NTT GB/s,
+NTT+LDE+commit end to end) ride in `extra`.
+
+roofline   : dominant kernel = k_leaf_subtree (one 2^K-leaf Merkle subtree per lane: Blake2b-512 leaf +
+             node compressions).  It is integer-VALU bound, not HBM bound, so `roofline`
+             prices it against the VALU issue peak and `roofline_hbm` gives the same launch against HBM.
+cpu_baseline: the reference-faithful CPU port (oracle mode 1: I320 schoolbook multiply + Knuth division,
+             ext-Euclid per fold element, sequential Blake2b Merkle — SURVEY.md §8d B1), 1 thread, on a
+             bounded sample.  The Rust reference itself cannot be built (no cargo/rustc on this image).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import stark_anatomy_amd as sa  # noqa: E402  (fails loudly without the HIP extension)
+from stark_anatomy_amd import _lib  # noqa: E402
+from stark_anatomy_amd.context import _u8p, _u64p, scalar  # noqa: E402
+
+# VALU issue peak derived from MI355X_MICROARCH.md: 157.3 TFLOP/s FP32 vector = 2 flop x 78.6e12 lane-ops/s
+# (256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz); simple 32-bit integer VALU ops issue at that rate.
+VALU_PEAK_OPS = 78.6e12
+HBM_PEAK_BPS = 8.0e12
+# Algorithmic 32-bit VALU ops per Blake2b-512 compression on CDNA4 (DESIGN.md "Roofline"):
+# 96 G x (6 add64 x 2 + 4 xor64 x 2 + rotations 0+2+2+2) = 2496, + 24 for init/feed-forward.
+OPS_NODE = 2520
+# leaf: 14 of the 16 message words are zero, so 14 of the 16 message additions per round fold away.
+OPS_LEAF = 2520 - 12 * 14 * 2
+
+
+def random_elems(n, seed):
+    """n canonical field elements: random u128 reduced mod p on the GPU (FieldElement::new, field.rs:30-35)."""
+    rng = np.random.default_rng(seed)
+    raw = np.frombuffer(rng.bytes(16 * n), dtype=np.uint64).reshape(n, 2)
+    return raw
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=24, help="log2 of the FRI domain (codeword length)")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stream = torch.cuda.Stream(device=local_rank)
+    ctx = sa.Context(local_rank, stream=stream.cuda_stream)
+    H = ctx.handle
+    log_n = args.log_n
+    N = 1 << log_n
+
+    # ---- synthetic codeword, resident in HBM before the timed region ----
+    def resident_codeword(n, seed):
+        raw = random_elems(n, seed)
+        red = np.empty_like(raw)
+        _lib.check(_lib.lib.sh_fp_new(H, _u64p(np.ascontiguousarray(raw)), _u64p(red), n))
+        return ctx.alloc(n * 16).upload(red)
+
+    params = _lib.FriParams()
+    params.expansion, params.num_colinearity_tests = 4, 17
+    params.offset[0], params.offset[1] = sa.GENERATOR & 0xFFFFFFFFFFFFFFFF, sa.GENERATOR >> 64
+
+    import ctypes as C
+
+    def commit(dbuf, n):
+        R = int(_lib.lib.sh_fri_num_rounds(n, 4, 17))
+        roots = np.zeros((max(R, 1), 64), dtype=np.uint8)
+        last = np.empty((n >> max(R - 1, 0), 2), dtype=np.uint64)
+        last_len = C.c_size_t(0)
+        ps = sa.ProofStream()
+        _lib.check(_lib.lib.sh_dev_fri_commit_proofstream(H, dbuf.ptr, n, C.byref(params), ps.handle, _u8p(roots), _u64p(last), C.byref(last_len)))
+        return roots, ps
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    d_cw = resident_codeword(N, 1000 + rank)
+    dt = timed(lambda: commit(d_cw, N), args.steps, args.warmup)
+    value = world * N * args.steps / dt
+    ms_per_step = 1e3 * dt / args.steps
+
+    out = {
+        "metric": "FRI commit field-elems/s", "value": value, "unit": "field-elems/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u128 (4x u32 Montgomery limbs) + u64 Blake2b",
+        "data": "synthetic",
+        "config": {"workload": f"full FRI commit of one resident 2^{log_n}-element codeword per GPU "
+                               f"(expansion 4, 17 colinearity tests, offset g: {int(_lib.lib.sh_fri_num_rounds(N, 4, 17))} rounds, "
+                               "Blake2b-512 Merkle roots, SHA-256/JSON transcript on host)",
+                   "domain": N, "per_gpu_codewords": 1, "sharding": "independent commits per rank, no collective"},
+    }
+
+    extra = {}
+    if not args.no_extra:
+        # ---- dominant kernel, timed with events on the stream it is launched on ----
+        K = max(0, min(3, log_n - 18))
+        n_out = N >> K
+        d_dig = ctx.alloc(n_out * 64)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        with torch.cuda.stream(stream):
+            _lib.check(_lib.lib.sh_dev_merkle_subtrees(H, d_cw.ptr, n_out, K, d_dig.ptr))
+            ev0.record(stream)
+            for _ in range(reps):
+                _lib.check(_lib.lib.sh_dev_merkle_subtrees(H, d_cw.ptr, n_out, K, d_dig.ptr))
+            ev1.record(stream)
+        torch.cuda.synchronize()
+        k_ms = ev0.elapsed_time(ev1) / reps
+        comp_leaf, comp_node = N, N - n_out
+        ops = comp_leaf * OPS_LEAF + comp_node * OPS_NODE
+        achieved = ops / (k_ms * 1e-3)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"k_leaf_subtree_log{log_n}")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "valu", "kernel": "k_leaf_subtree", "achieved": achieved / 1e12, "peak": VALU_PEAK_OPS / 1e12,
+                           "unit": "Tops/s (32-bit integer VALU lane-ops)", "frac": achieved / VALU_PEAK_OPS, "traffic": traffic,
+                           "launch_ms": k_ms, "units_per_launch": {"leaves": N, "leaf_compressions": comp_leaf, "node_compressions": comp_node},
+                           "ops_per_leaf_compression": OPS_LEAF, "ops_per_node_compression": OPS_NODE,
+                           "compressions_per_s": (comp_leaf + comp_node) / (k_ms * 1e-3)}
+        hbm_bytes = N * 16 + n_out * 64
+        out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_leaf_subtree", "achieved": hbm_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_BPS / 1e9,
+                               "unit": "GB/s", "frac": hbm_bytes / (k_ms * 1e-3) / HBM_PEAK_BPS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": hbm_bytes}
+        d_dig.free()
+
+        # ---- NTT GB/s at the same size (32·n bytes = one read + one write per point) ----
+        host_cw = d_cw.download(np.uint64, (N, 2))
+        d_x = ctx.alloc(N * 16).upload(host_cw)
+        ntt_steps = max(3, args.steps)
+        dt_ntt = timed(lambda: (_lib.check(_lib.lib.sh_dev_ntt(H, d_x.ptr, log_n, 0)), ctx.sync()), ntt_steps, 1)
+        extra[f"ntt_2^{log_n}_GBps"] = world * 32.0 * N * ntt_steps / dt_ntt / 1e9
+        extra[f"ntt_2^{log_n}_ms"] = 1e3 * dt_ntt / ntt_steps
+
+        # ---- north-star end to end: n = N/4 coefficients -> coset LDE (NTT) -> full commit ----
+        d_coef = ctx.alloc((N // 4) * 16).upload(host_cw[:N // 4])
+
+        def e2e():
+            _lib.check(_lib.lib.sh_dev_coset_lde(H, d_coef.ptr, log_n - 2, 2, _u64p(scalar(sa.GENERATOR)), d_x.ptr))
+            commit(d_x, N)
+        dt_e2e = timed(e2e, max(3, args.steps // 2), 1)
+        extra[f"lde_plus_commit_2^{log_n}_elems_per_s"] = world * N * max(3, args.steps // 2) / dt_e2e
+        d_x.free(); d_coef.free()
+
+        # ---- the other domain the metric names ----
+        other = 20 if log_n != 20 else 24
+        d_o = resident_codeword(1 << other, 2000 + rank)
+        so = max(args.steps, 10) if other == 20 else max(3, args.steps // 2)
+        dt_o = timed(lambda: commit(d_o, 1 << other), so, 2)
+        extra[f"fri_commit_2^{other}_elems_per_s"] = world * (1 << other) * so / dt_o
+        extra[f"fri_commit_2^{other}_ms"] = 1e3 * dt_o / so
+        d_o.free()
+    out["extra"] = extra
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import coracle as co      # checker used as the CPU baseline leg only
+        log_s = 18
+        cw = co.splitmix_elems(3, 1 << log_s)
+        t0 = time.perf_counter()
+        co.fri_commit(cw, 4, 17, sa.GENERATOR, mode=1)
+        t1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        co.fri_commit(cw, 4, 17, sa.GENERATOR, mode=0)
+        t2 = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": (1 << log_s) / t1, "unit": "field-elems/s", "cores": 1, "kind": "port",
+                               "sample": f"one full FRI commit at N=2^{log_s} (same parameters), reference-faithful port: I320 5-limb "
+                                         "multiply + Knuth division per field op, ext-Euclid per fold element, sequential Blake2b Merkle "
+                                         f"({t1:.1f} s); the Rust reference cannot be built here (no cargo/rustc)",
+                               "optimized_port_1core_elems_per_s": (1 << log_s) / t2, "host_cpus": os.cpu_count()}
+
+    if rank == 0:
+        print(json.dumps(out))
+    d_cw.free()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

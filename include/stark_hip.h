@@ -101,6 +101,10 @@ int32_t sh_dev_hash_leaves(sh_ctx* ctx, const uint64_t* d_elems, size_t L, uint8
 /* fused: root of the tree whose leaves are sh_hash_leaves(elems) (what one FRI round commits to). */
 int32_t sh_merkle_commit_elems(sh_ctx* ctx, const uint64_t* elems, size_t L, uint8_t root[64]);
 int32_t sh_dev_merkle_commit_elems(sh_ctx* ctx, const uint64_t* d_elems, size_t L, uint8_t root[64]);
+/* d_out[i] = Merkle root of the 2^K-leaf subtree over leafhash(d_elems[i·2^K .. (i+1)·2^K)), 0 <= K <= 4: the
+ * bottom K+1 levels of merkle.rs:48-60 for n_out independent subtrees in one launch (one subtree per lane).
+ * This is the dominant kernel of the commit; also the building block for batches of small commits. */
+int32_t sh_dev_merkle_subtrees(sh_ctx* ctx, const uint64_t* d_elems, size_t n_out, uint32_t K, uint8_t* d_out);
 /* `MerkleTree::open(index)`, merkle.rs:70-108: path[0] = sibling leaf … path[log2 L − 1] = sibling
  * of the root's child; *path_len = log2 L.  SH_EBOUNDS if index >= L or L < 2 (merkle.rs:75,104). */
 int32_t sh_merkle_open(sh_ctx* ctx, const uint8_t* leaves, size_t L, size_t index, uint8_t* path, size_t* path_len);

@@ -448,6 +448,14 @@ int32_t sh_hash_leaves(sh_ctx* c, const uint64_t* elems, size_t L, uint8_t* out)
     HIPCHK(hipStreamSynchronize(c->stream));
     return SH_OK;
 }
+int32_t sh_dev_merkle_subtrees(sh_ctx* c, const uint64_t* d_elems, size_t n_out, uint32_t K, uint8_t* d_out) {
+    CTXCHK(c);
+    if (n_out == 0) return SH_OK;
+    if (!d_elems || !d_out) return sh_fail(SH_EINVAL, "sh_dev_merkle_subtrees: null pointer");
+    if (K > 4) return sh_fail(SH_EINVAL, "sh_dev_merkle_subtrees: K must be <= 4");
+    HIPCHK(launch_leaf_subtree((const fp*)d_elems, (digest64*)d_out, n_out, K, c->stream));
+    return SH_OK;
+}
 int32_t sh_dev_merkle_commit_elems(sh_ctx* c, const uint64_t* d_elems, size_t L, uint8_t root[64]) {
     CTXCHK(c);
     if (!d_elems || !root) return sh_fail(SH_EINVAL, "sh_dev_merkle_commit_elems: null pointer");

@@ -1,0 +1,92 @@
+// valu_peak.hip — micro-benchmark of the gfx950 integer VALU issue rates that bound the Blake2b and
+// Montgomery kernels ("measure, don't assume" the quarter-rate multiply and the 64-bit add).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/valu_peak.hip -o tools/valu_peak ; run on the GPU box.
+// Prints lane-ops/s per instruction kind with every SIMD holding `waves` waves.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+// 8 independent chains x 8 instructions per asm block
+#define REP8(INS) INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7)
+#define BLOCK(INS) REP8(INS) REP8(INS) REP8(INS) REP8(INS) REP8(INS) REP8(INS) REP8(INS) REP8(INS)
+
+#define XOR_I(i) "v_xor_b32 %" #i ", %" #i ", %8\n"
+#define ADD_I(i) "v_add_u32 %" #i ", %" #i ", %8\n"
+#define ALIGN_I(i) "v_alignbit_b32 %" #i ", %" #i ", %8, 7\n"
+#define PERM_I(i) "v_alignbyte_b32 %" #i ", %" #i ", %8, 3\n"
+#define MULLO_I(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
+#define MULHI_I(i) "v_mul_hi_u32 %" #i ", %" #i ", %8\n"
+#define ADD3_I(i) "v_add3_u32 %" #i ", %" #i ", %8, %8\n"
+#define XAD_I(i) "v_xad_u32 %" #i ", %" #i ", %8, %8\n"
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k32(uint32_t* out, int iters, uint32_t seed) {
+    uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    uint32_t b = seed | 1;
+    for (int it = 0; it < iters; ++it) {
+        if (KIND == 0) asm volatile(BLOCK(XOR_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 1) asm volatile(BLOCK(ADD_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 2) asm volatile(BLOCK(ALIGN_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 3) asm volatile(BLOCK(PERM_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 4) asm volatile(BLOCK(MULLO_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 5) asm volatile(BLOCK(MULHI_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 6) asm volatile(BLOCK(ADD3_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 7) asm volatile(BLOCK(XAD_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+
+#define LSHLADD_I(i) "v_lshl_add_u64 %" #i ", %" #i ", 0, %8\n"
+#define MAD64_I(i) "v_mad_u64_u32 %" #i ", vcc, %9, %10, %" #i "\n"
+#define ADDCO_I(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %9\nv_addc_co_u32 %" #i ", vcc, %" #i ", %10, vcc\n"
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k64(uint64_t* out, int iters, uint32_t seed) {
+    uint64_t a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    uint64_t b = ((uint64_t)seed << 32) | 12345;
+    uint32_t x = seed | 1, y = seed * 7 + 3;
+    for (int it = 0; it < iters; ++it) {
+        if (KIND == 0) asm volatile(BLOCK(LSHLADD_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 1) asm volatile(BLOCK(MAD64_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(x), "v"(y) : "vcc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+
+template <class F>
+static double time_ms(F launch) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    launch();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    launch();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
+int main() {
+    const int iters = 4000;
+    void* buf;
+    CHK(hipMalloc(&buf, (size_t)256 * 8 * 4 * 256 * 8));
+    const char* n32[] = {"v_xor_b32", "v_add_u32", "v_alignbit_b32", "v_alignbyte_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_add3_u32", "v_xad_u32"};
+    const char* n64[] = {"v_lshl_add_u64", "v_mad_u64_u32"};
+    for (int wps = 1; wps <= 8; wps *= 2) {                // waves per SIMD
+        const int blocks = 256 * wps;                      // 256 CUs x (wps*4 waves = wps blocks of 256 threads)
+        const double lane_ops = (double)blocks * 256 * iters * 64;
+        printf("--- %d wave(s) per SIMD (%d blocks of 256) ---\n", wps, blocks);
+        double ms;
+#define RUN32(K) ms = time_ms([&] { hipLaunchKernelGGL(k32<K>, dim3(blocks), dim3(256), 0, 0, (uint32_t*)buf, iters, 7u); }); \
+        printf("%-16s %8.3f ms  %8.2f T lane-ops/s\n", n32[K], ms, lane_ops / ms / 1e9);
+        RUN32(0) RUN32(1) RUN32(2) RUN32(3) RUN32(4) RUN32(5) RUN32(6) RUN32(7)
+#define RUN64(K) ms = time_ms([&] { hipLaunchKernelGGL(k64<K>, dim3(blocks), dim3(256), 0, 0, (uint64_t*)buf, iters, 7u); }); \
+        printf("%-16s %8.3f ms  %8.2f T lane-ops/s\n", n64[K], ms, lane_ops / ms / 1e9);
+        RUN64(0) RUN64(1)
+    }
+    CHK(hipDeviceSynchronize());
+    return 0;
+}
