@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <map>
 #include <new>
@@ -40,7 +41,12 @@ struct sh_ctx {
     size_t scratch_bytes[NUM_SCRATCH] = {};
     uint32_t* d_flag = nullptr;
     digest64* d_root = nullptr;
-    uint8_t* h_pinned = nullptr;                 // 256 B of pinned host memory (root / flag mailbox)
+    uint8_t* h_pinned = nullptr;                 // 256 B of pinned host memory (staging for small D2H copies)
+    uint8_t* h_mail = nullptr;                   // pinned, device-mapped mailbox: root[64] | seq (u32)
+    uint64_t* d_mail = nullptr;                  // device view of h_mail
+    uint32_t mail_seq = 0;                       // last sequence number handed to a kernel
+    bool mail_pending = false;                   // the root of the last reduction arrives through the mailbox
+    uint64_t mail_fallbacks = 0;
     std::map<uint32_t, fp*> tw_cache;            // key = log_n*2 + inverse
 };
 
@@ -132,6 +138,8 @@ int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out) {
     e = hipMalloc(&c->d_flag, 256);
     if (e == hipSuccess) e = hipMalloc(&c->d_root, 256);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_pinned, 256, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_mail, 256, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) { memset(c->h_mail, 0, 256); e = hipHostGetDevicePointer((void**)&c->d_mail, c->h_mail, 0); }
     if (e != hipSuccess) { sh_ctx_destroy(c); return sh_failf(SH_EHIP, "context allocation failed: %s", hipGetErrorString(e)); }
     *out = c;
     return SH_OK;
@@ -140,11 +148,13 @@ int32_t sh_ctx_destroy(sh_ctx* c) {
     if (!c) return SH_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (getenv("STARK_HIP_DEBUG")) fprintf(stderr, "[stark_hip] ctx %p: mailbox roots %u, fallbacks %llu\n", (void*)c, c->mail_seq, (unsigned long long)c->mail_fallbacks);
     for (auto& kv : c->tw_cache) (void)hipFree(kv.second);
     for (int i = 0; i < NUM_SCRATCH; ++i) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_root) (void)hipFree(c->d_root);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_mail) (void)hipHostFree(c->h_mail);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SH_OK;
@@ -235,27 +245,42 @@ static int32_t dev_ntt(sh_ctx* c, fp* d_data, uint32_t log_n, bool inverse) {
 }
 
 // ------------------------------------------------------------------ Merkle
-// Reduce `count` (power of two) digests at `cur` to the root in c->d_root.  `cur` is not modified.
+// Reduce `count` (power of two) digests at `cur` to the root in c->d_root (and the host mailbox).  `cur` is not
+// modified.  Wide levels: one 2^K-node subtree per lane (throughput).  From 2^17 nodes down: four lanes per
+// compression, levels in LDS (latency), in at most two launches.
+#define QUAD_MAX_LOG_COUNT 17
 static int32_t reduce_digests(sh_ctx* c, const digest64* cur, size_t count) {
-    void *bufA, *bufB;
-    if (count > MERKLE_TAIL_MAX) {
-        SHCHK(ensure_scratch(c, SCR_DIG_B, (count >> 1) * sizeof(digest64), &bufB));
-        bufA = nullptr;
-        bool use_b = true;
-        while (count > MERKLE_TAIL_MAX) {
-            uint32_t lg = ilog2(count);
-            uint32_t K = lg - 9 < 3 ? lg - 9 : 3;                 // leave >= 512 nodes for the LDS tail
-            digest64* out;
-            if (use_b) out = (digest64*)bufB;
-            else {
-                if (!bufA) SHCHK(ensure_scratch(c, SCR_DIG_A, (count >> K) * sizeof(digest64), &bufA));
-                out = (digest64*)bufA;
-            }
-            HIPCHK(launch_node_subtree(cur, out, count >> K, K, c->stream));
-            cur = out; count >>= K; use_b = !use_b;
-        }
+    uint32_t lg = ilog2(count);
+    c->mail_pending = false;
+    if (lg == 0) {
+        HIPCHK(hipMemcpyAsync(c->d_root, cur, sizeof(digest64), hipMemcpyDeviceToDevice, c->stream));
+        return SH_OK;
     }
-    HIPCHK(launch_merkle_tail(cur, c->d_root, count, c->stream));
+    bool use_b = true;                         // ping-pong SCR_DIG_B / SCR_DIG_A; the caller's input may live in SCR_DIG_A
+    auto next_buf = [&](size_t n_out, digest64** out) -> int32_t {
+        void* b;
+        SHCHK(ensure_scratch(c, use_b ? SCR_DIG_B : SCR_DIG_A, n_out * sizeof(digest64), &b));
+        use_b = !use_b;
+        *out = (digest64*)b;
+        return SH_OK;
+    };
+    while (lg > QUAD_MAX_LOG_COUNT) {
+        const uint32_t K = lg - QUAD_MAX_LOG_COUNT < 3 ? lg - QUAD_MAX_LOG_COUNT : 3;
+        digest64* out;
+        SHCHK(next_buf(count >> K, &out));
+        HIPCHK(launch_node_subtree(cur, out, count >> K, K, c->stream));
+        cur = out; count >>= K; lg -= K;
+    }
+    if (lg > QUAD_MAX_LOG_CHUNK) {
+        const uint32_t first = (lg + 1) / 2;
+        digest64* out;
+        SHCHK(next_buf(count >> first, &out));
+        HIPCHK(launch_quad_reduce(cur, out, count, first, nullptr, 0, c->stream));
+        cur = out; count >>= first; lg -= first;
+    }
+    if (++c->mail_seq == 0) c->mail_seq = 1;
+    HIPCHK(launch_quad_reduce(cur, c->d_root, count, lg, c->d_mail, c->mail_seq, c->stream));
+    c->mail_pending = true;
     return SH_OK;
 }
 static uint32_t leaf_subtree_k(uint32_t log_L) {
@@ -265,14 +290,33 @@ static uint32_t leaf_subtree_k(uint32_t log_L) {
 }
 // root of merkle(leafhash(elems[0..L))) -> c->d_root (enqueued, not synchronised)
 static int32_t merkle_root_from_elems(sh_ctx* c, const fp* d_elems, size_t L) {
-    if (L == 1) { HIPCHK(launch_hash_leaves(d_elems, c->d_root, 1, c->stream)); return SH_OK; }
+    if (L == 1) { c->mail_pending = false; HIPCHK(launch_hash_leaves(d_elems, c->d_root, 1, c->stream)); return SH_OK; }
     const uint32_t K = leaf_subtree_k(ilog2(L));
     void* dig;
     SHCHK(ensure_scratch(c, SCR_DIG_A, (L >> K) * sizeof(digest64), &dig));
     HIPCHK(launch_leaf_subtree(d_elems, (digest64*)dig, L >> K, K, c->stream));
     return reduce_digests(c, (const digest64*)dig, L >> K);
 }
+// Bring the root of the last reduction to the host.  Fast path: the last kernel wrote root + sequence number
+// into pinned host memory; poll for it (no interrupt-driven stream synchronise on the serial FRI chain).
 static int32_t fetch_root(sh_ctx* c, uint8_t root[64]) {
+    if (c->mail_pending) {
+        c->mail_pending = false;
+        const uint32_t* flag = reinterpret_cast<const uint32_t*>(c->h_mail + 64);
+        uint64_t spins = 0;
+        bool got = false;
+        for (;;) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->mail_seq) { got = true; break; }
+            if ((++spins & 0xfff) == 0) {
+                hipError_t e = hipStreamQuery(c->stream);
+                if (e == hipSuccess) { got = (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->mail_seq); break; }
+                if (e != hipErrorNotReady) return sh_failf(SH_EHIP, "stream failed while waiting for a Merkle root: %s", hipGetErrorString(e));
+            }
+            __builtin_ia32_pause();
+        }
+        if (got) { memcpy(root, c->h_mail, 64); return SH_OK; }
+        ++c->mail_fallbacks;                   // stream drained but the mailbox write is not visible: take the copy path
+    }
     HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_root, 64, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     memcpy(root, c->h_pinned, 64);
