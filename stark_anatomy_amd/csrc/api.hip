@@ -350,6 +350,7 @@ static int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_
         if (R > 1) SHCHK(ensure_scratch(c, SCR_IO_A, (N / 2) * sizeof(fp), &bufX));
         if (R > 2) SHCHK(ensure_scratch(c, SCR_IO_B, (N / 4) * sizeof(fp), &bufY));
         const fp inv2 = fp_inv(fp_make(2, 0, 0, 0));
+        fp off_inv = fp_inv(off);                  // (off^(2^r))^-1 = (off^-1)^(2^r): one inversion for the whole commit
         uint8_t root[64];
         SHCHK(merkle_root_from_elems(c, cur, L));
         SHCHK(fetch_root(c, root));
@@ -362,7 +363,7 @@ static int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_
             const fp alpha = fp_load_host(alpha_w);
             if (!fp_is_canonical(alpha)) return sh_fail(SH_EINVAL, "fri_commit: callback returned a non-canonical alpha");
             // c0 = alpha · 2^-1 · offset^-1, kept in Montgomery form for the kernel
-            const fp c0 = fp_mul(fp_mul(alpha, inv2), fp_inv(off));
+            const fp c0 = fp_mul(fp_mul(alpha, inv2), off_inv);
             const size_t half = L / 2;
             fp* next = (fp*)((r & 1) ? bufY : bufX);
             uint32_t K = leaf_subtree_k(ilog2(half));
@@ -372,7 +373,7 @@ static int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_
             SHCHK(reduce_digests(c, (const digest64*)dig, half >> K));
             SHCHK(fetch_root(c, root));
             cur = next; L = half;
-            off = fp_mul(off, off);
+            off_inv = fp_mul(off_inv, off_inv);
         }
     }
     HIPCHK(hipMemcpyAsync(last_out, cur, L * sizeof(fp), hipMemcpyDeviceToHost, c->stream));

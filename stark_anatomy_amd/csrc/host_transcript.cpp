@@ -121,10 +121,20 @@ void host_blake2b512(const uint8_t* in, size_t len, uint8_t out[64]) {
 }
 
 // ------------------------------------------------------------------ ProofStream (proof_stream.rs:17-69)
+struct Sha256Ctx;
 struct sh_proofstream {
     std::vector<std::string> items;   // compact-JSON fragment per item
     size_t read_index = 0;
+    // Running SHA-256 over "[" item0 "," item1 ... for the first `absorbed` items: the stream is append-only, so
+    // prover_fiat_shamir (proof_stream.rs:51-56, re-serialises and re-hashes everything each call) only has to
+    // absorb the new items and a closing "]" on a copy.  Same digest, O(new bytes) instead of O(stream).
+    Sha256Ctx* running = nullptr;
+    size_t absorbed = 0;
+    ~sh_proofstream();
 };
+
+struct Sha256Ctx { Sha256 h; };
+sh_proofstream::~sh_proofstream() { delete running; }
 
 namespace {
 void append_u64_dec(std::string& s, uint64_t v) {
@@ -331,8 +341,20 @@ int32_t sh_proofstream_deserialize(const uint8_t* bytes, size_t len, sh_proofstr
 }
 int32_t sh_proofstream_prover_fiat_shamir(sh_proofstream* ps, uint8_t out[32]) {                   // proof_stream.rs:51-56
     if (!ps || !out) return sh_fail(SH_EINVAL, "sh_proofstream_prover_fiat_shamir: null pointer");
-    std::string s = serialize_items(ps->items, ps->items.size());
-    host_sha256((const uint8_t*)s.data(), s.size(), out);
+    if (!ps->running) {
+        ps->running = new (std::nothrow) Sha256Ctx();
+        if (!ps->running) return sh_fail(SH_ENOMEM, "sh_proofstream_prover_fiat_shamir: out of memory");
+        ps->running->h.update((const uint8_t*)"[", 1);
+        ps->absorbed = 0;
+    }
+    for (; ps->absorbed < ps->items.size(); ++ps->absorbed) {
+        if (ps->absorbed) ps->running->h.update((const uint8_t*)",", 1);
+        const std::string& it = ps->items[ps->absorbed];
+        ps->running->h.update((const uint8_t*)it.data(), it.size());
+    }
+    Sha256 fin = ps->running->h;                 // copy the midstate, close the array on the copy
+    fin.update((const uint8_t*)"]", 1);
+    fin.finish(out);
     return SH_OK;
 }
 int32_t sh_proofstream_verifier_fiat_shamir(sh_proofstream* ps, uint8_t out[32]) {                 // proof_stream.rs:58-64
