@@ -15,6 +15,9 @@
 #include "kernels.h"
 
 #define SUBTREE_KMAX 4
+#ifndef SUBTREE_WAVES
+#define SUBTREE_WAVES 1
+#endif
 
 // Depth-first reduction of 2^K items produced by `leaf(i)` (i ascending) to one digest.
 // Every loop bound and stack index is wave-uniform.
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void k_hash_leaves(const fp* __restrict__ elem
     }
 }
 
-__global__ __launch_bounds__(256) void k_leaf_subtree(const fp* __restrict__ elems, digest64* __restrict__ out, size_t n_out, uint32_t K) {
+__global__ __launch_bounds__(256, SUBTREE_WAVES) void k_leaf_subtree(const fp* __restrict__ elems, digest64* __restrict__ out, size_t n_out, uint32_t K) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     const fp* base = elems + (i << K);
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void k_leaf_subtree(const fp* __restrict__ ele
     store_digest(out + i, d);
 }
 
-__global__ __launch_bounds__(256) void k_node_subtree(const digest64* __restrict__ in, digest64* __restrict__ out, size_t n_out, uint32_t K) {
+__global__ __launch_bounds__(256, SUBTREE_WAVES) void k_node_subtree(const digest64* __restrict__ in, digest64* __restrict__ out, size_t n_out, uint32_t K) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     const digest64* base = in + (i << K);
@@ -149,7 +152,7 @@ __device__ __forceinline__ fp load_tw(const fp* __restrict__ tw, uint32_t log_n,
 }
 
 // Fused FRI round: fold, write the folded codeword, and hash it into 2^K-leaf subtree digests.
-__global__ __launch_bounds__(256) void k_fold_leaf_subtree(const fp* __restrict__ cw, size_t half, fp c0_mont,
+__global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const fp* __restrict__ cw, size_t half, fp c0_mont,
                                                            const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
                                                            fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out, uint32_t K) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

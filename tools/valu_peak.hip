@@ -20,6 +20,7 @@
 #define MULLO_I(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
 #define MULHI_I(i) "v_mul_hi_u32 %" #i ", %" #i ", %8\n"
 #define ADD3_I(i) "v_add3_u32 %" #i ", %" #i ", %8, %8\n"
+#define ADDCOP_I(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\nv_addc_co_u32 %" #i ", vcc, %" #i ", %8, vcc\n"
 #define XAD_I(i) "v_xad_u32 %" #i ", %" #i ", %8, %8\n"
 
 template <int KIND>
@@ -35,13 +36,17 @@ __global__ __launch_bounds__(256) void k32(uint32_t* out, int iters, uint32_t se
         if (KIND == 5) asm volatile(BLOCK(MULHI_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
         if (KIND == 6) asm volatile(BLOCK(ADD3_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
         if (KIND == 7) asm volatile(BLOCK(XAD_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 8) asm volatile(BLOCK(ADDCOP_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
 
 #define LSHLADD_I(i) "v_lshl_add_u64 %" #i ", %" #i ", 0, %8\n"
 #define MAD64_I(i) "v_mad_u64_u32 %" #i ", vcc, %9, %10, %" #i "\n"
-#define ADDCO_I(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %9\nv_addc_co_u32 %" #i ", vcc, %" #i ", %10, vcc\n"
+#define SHR64_I(i) "v_lshrrev_b64 %" #i ", 24, %" #i "\n"
+#define SHL64_I(i) "v_lshlrev_b64 %" #i ", 1, %" #i "\n"
+#define MOV64_I(i) "v_mov_b64 %" #i ", %8\n"
+#define ADDCO_I(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\nv_addc_co_u32 %" #i ", vcc, %" #i ", %8, vcc\n"
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k64(uint64_t* out, int iters, uint32_t seed) {
@@ -50,6 +55,9 @@ __global__ __launch_bounds__(256) void k64(uint64_t* out, int iters, uint32_t se
     uint32_t x = seed | 1, y = seed * 7 + 3;
     for (int it = 0; it < iters; ++it) {
         if (KIND == 0) asm volatile(BLOCK(LSHLADD_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 2) asm volatile(BLOCK(SHR64_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 3) asm volatile(BLOCK(SHL64_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 4) asm volatile(BLOCK(MOV64_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
         if (KIND == 1) asm volatile(BLOCK(MAD64_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(x), "v"(y) : "vcc");
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
@@ -73,19 +81,19 @@ int main() {
     const int iters = 4000;
     void* buf;
     CHK(hipMalloc(&buf, (size_t)256 * 8 * 4 * 256 * 8));
-    const char* n32[] = {"v_xor_b32", "v_add_u32", "v_alignbit_b32", "v_alignbyte_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_add3_u32", "v_xad_u32"};
-    const char* n64[] = {"v_lshl_add_u64", "v_mad_u64_u32"};
-    for (int wps = 1; wps <= 8; wps *= 2) {                // waves per SIMD
+    const char* n32[] = {"v_xor_b32", "v_add_u32", "v_alignbit_b32", "v_alignbyte_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_add3_u32", "v_xad_u32", "add_co+addc (x2 instr)"};
+    const char* n64[] = {"v_lshl_add_u64", "v_mad_u64_u32", "v_lshrrev_b64", "v_lshlrev_b64", "v_mov_b64"};
+    for (int wps = 1; wps <= 8; wps *= 2) if (wps != 2) {                // waves per SIMD
         const int blocks = 256 * wps;                      // 256 CUs x (wps*4 waves = wps blocks of 256 threads)
         const double lane_ops = (double)blocks * 256 * iters * 64;
         printf("--- %d wave(s) per SIMD (%d blocks of 256) ---\n", wps, blocks);
         double ms;
 #define RUN32(K) ms = time_ms([&] { hipLaunchKernelGGL(k32<K>, dim3(blocks), dim3(256), 0, 0, (uint32_t*)buf, iters, 7u); }); \
         printf("%-16s %8.3f ms  %8.2f T lane-ops/s\n", n32[K], ms, lane_ops / ms / 1e9);
-        RUN32(0) RUN32(1) RUN32(2) RUN32(3) RUN32(4) RUN32(5) RUN32(6) RUN32(7)
+        RUN32(0) RUN32(1) RUN32(2) RUN32(3) RUN32(4) RUN32(5) RUN32(6) RUN32(7) RUN32(8)
 #define RUN64(K) ms = time_ms([&] { hipLaunchKernelGGL(k64<K>, dim3(blocks), dim3(256), 0, 0, (uint64_t*)buf, iters, 7u); }); \
         printf("%-16s %8.3f ms  %8.2f T lane-ops/s\n", n64[K], ms, lane_ops / ms / 1e9);
-        RUN64(0) RUN64(1)
+        RUN64(0) RUN64(1) RUN64(2) RUN64(3) RUN64(4)
     }
     CHK(hipDeviceSynchronize());
     return 0;
