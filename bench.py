@@ -195,6 +195,23 @@ def main():
         extra[f"lde_plus_commit_2^{log_n}_elems_per_s"] = world * N * max(3, args.steps // 2) / dt_e2e
         d_x.free(); d_coef.free()
 
+        # ---- BASELINE config 4 (per-GPU share): 128 independent 2^14 commits in lock step ----
+        Bb, nb = 128, 1 << 14
+        d_b = resident_codeword(Bb * nb, 3000 + rank)
+        Rb = int(_lib.lib.sh_fri_num_rounds(nb, 4, 17))
+        roots_b = np.zeros((Bb, Rb, 64), dtype=np.uint8)
+        last_b = np.empty((Bb, nb >> (Rb - 1), 2), dtype=np.uint64)
+
+        def batch_commit():
+            pss = [sa.ProofStream() for _ in range(Bb)]
+            handles = (_lib.ps_t * Bb)(*[p.handle for p in pss])
+            ll = C.c_size_t(0)
+            _lib.check(_lib.lib.sh_dev_fri_commit_batch(H, d_b.ptr, Bb, nb, C.byref(params), handles, _u8p(roots_b), _u64p(last_b), C.byref(ll)))
+        dt_b = timed(batch_commit, max(5, args.steps), 2)
+        extra["batch_128x2^14_elems_per_s"] = world * Bb * nb * max(5, args.steps) / dt_b
+        extra["batch_128x2^14_ms"] = 1e3 * dt_b / max(5, args.steps)
+        d_b.free()
+
         # ---- the other domain the metric names ----
         other = 20 if log_n != 20 else 24
         d_o = resident_codeword(1 << other, 2000 + rank)

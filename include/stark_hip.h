@@ -162,6 +162,15 @@ int32_t sh_fri_commit_proofstream(sh_ctx* ctx, const uint64_t* codeword, size_t 
 int32_t sh_dev_fri_commit_proofstream(sh_ctx* ctx, const uint64_t* d_codeword, size_t N, const sh_fri_params* params,
                                       sh_proofstream* ps, uint8_t* roots_out, uint64_t* last_codeword_out, size_t* last_len);
 
+/* Batch of B independent commits of equal length N (BASELINE config 4: 1024 x 2^14), codewords back to back
+ * (B*N elements).  Rounds run in lock step: every kernel covers all B codewords, each codeword has its own
+ * transcript `streams[b]` and challenge.  Results are exactly those of B separate sh_fri_commit_proofstream calls:
+ * roots_out[(b*R + r)*64 ..], last_codewords_out[b*last_len ..], and each stream gets its R roots + last codeword. */
+int32_t sh_fri_commit_batch(sh_ctx* ctx, const uint64_t* codewords, size_t B, size_t N, const sh_fri_params* params,
+                            sh_proofstream** streams, uint8_t* roots_out, uint64_t* last_codewords_out, size_t* last_len);
+int32_t sh_dev_fri_commit_batch(sh_ctx* ctx, const uint64_t* d_codewords, size_t B, size_t N, const sh_fri_params* params,
+                                sh_proofstream** streams, uint8_t* roots_out, uint64_t* last_codewords_out, size_t* last_len);
+
 /* ---------------- host-only scalar helpers (no GPU involved; used by the driver and the shim) ---------------- */
 int32_t sh_sha256(const uint8_t* in, size_t len, uint8_t out[32]);                      /* crate sha2, proof_stream.rs:52-55 */
 int32_t sh_blake2b512(const uint8_t* in, size_t len, uint8_t out[64]);                  /* crate blake2, merkle.rs:134-136   */

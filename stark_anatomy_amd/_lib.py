@@ -92,6 +92,8 @@ _PROTOS = {
     "sh_proofstream_verifier_fiat_shamir": (C.c_int32, [ps_t, u8p]),
     "sh_fri_commit_proofstream": (C.c_int32, [ctx_t, u64p, C.c_size_t, C.POINTER(FriParams), ps_t, u8p, u64p, szp]),
     "sh_dev_fri_commit_proofstream": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.POINTER(FriParams), ps_t, u8p, u64p, szp]),
+    "sh_fri_commit_batch": (C.c_int32, [ctx_t, u64p, C.c_size_t, C.c_size_t, C.POINTER(FriParams), C.POINTER(ps_t), u8p, u64p, szp]),
+    "sh_dev_fri_commit_batch": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(FriParams), C.POINTER(ps_t), u8p, u64p, szp]),
     "sh_sha256": (C.c_int32, [C.c_char_p, C.c_size_t, u8p]),
     "sh_blake2b512": (C.c_int32, [C.c_char_p, C.c_size_t, u8p]),
     "sh_merkle_verify": (C.c_int32, [u8p, u8p, u8p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int32)]),

@@ -31,8 +31,8 @@ int32_t sh_failf(int32_t code, const char* fmt, ...) {
 #define SHCHK(expr) do { int32_t _rc = (expr); if (_rc != SH_OK) return _rc; } while (0)
 
 // ------------------------------------------------------------------ context
-#define NUM_SCRATCH 6
-enum { SCR_IO_A = 0, SCR_IO_B = 1, SCR_IO_C = 2, SCR_WORK = 3, SCR_DIG_A = 4, SCR_DIG_B = 5 };
+#define NUM_SCRATCH 8
+enum { SCR_IO_A = 0, SCR_IO_B = 1, SCR_IO_C = 2, SCR_WORK = 3, SCR_DIG_A = 4, SCR_DIG_B = 5, SCR_ROOTS = 6, SCR_C0 = 7 };
 struct sh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -48,6 +48,8 @@ struct sh_ctx {
     bool mail_pending = false;                   // the root of the last reduction arrives through the mailbox
     uint64_t mail_fallbacks = 0;
     std::map<uint32_t, fp*> tw_cache;            // key = log_n*2 + inverse
+    uint8_t* h_batch = nullptr;                  // pinned staging for batched commits: roots (B*64) | c0 (B*16)
+    size_t h_batch_bytes = 0;
 };
 
 static int32_t ensure_scratch(sh_ctx* c, int slot, size_t bytes, void** out) {
@@ -155,6 +157,7 @@ int32_t sh_ctx_destroy(sh_ctx* c) {
     if (c->d_root) (void)hipFree(c->d_root);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
+    if (c->h_batch) (void)hipHostFree(c->h_batch);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SH_OK;
@@ -369,7 +372,7 @@ static int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_
             uint32_t K = leaf_subtree_k(ilog2(half));
             void* dig;
             SHCHK(ensure_scratch(c, SCR_DIG_A, (half >> K) * sizeof(digest64), &dig));
-            HIPCHK(launch_fold_leaf_subtree(cur, L, fp_to_mont(c0), tw_inv, log_N, r, next, (digest64*)dig, K, c->stream));
+            HIPCHK(launch_fold_leaf_subtree(cur, L, 1, nullptr, fp_to_mont(c0), tw_inv, log_N, r, next, (digest64*)dig, K, c->stream));
             SHCHK(reduce_digests(c, (const digest64*)dig, half >> K));
             SHCHK(fetch_root(c, root));
             cur = next; L = half;
@@ -379,6 +382,115 @@ static int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_
     HIPCHK(hipMemcpyAsync(last_out, cur, L * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *last_len = L;
+    return SH_OK;
+}
+
+// ------------------------------------------------------------------ batched FRI commit (lock-step rounds)
+// B independent codewords of equal length, back to back.  Every kernel of a round covers all B codewords, so the
+// serial root -> challenge -> fold chain is paid once per round for the whole batch instead of
+// once per commit: this is what makes small commits (config 4: 1024 x 2^14) throughput-bound.
+static int32_t reduce_digests_batch(sh_ctx* c, const digest64* cur, size_t count, size_t B, digest64* d_roots) {
+    uint32_t lg = ilog2(count);
+    if (lg == 0) {
+        HIPCHK(hipMemcpyAsync(d_roots, cur, B * sizeof(digest64), hipMemcpyDeviceToDevice, c->stream));
+        return SH_OK;
+    }
+    bool use_b = true;
+    while (lg > 0) {
+        const size_t total = B << lg;
+        const bool wide = total > ((size_t)1 << QUAD_MAX_LOG_COUNT);
+        const uint32_t step = wide ? (lg < 3 ? lg : 3) : (lg < QUAD_MAX_LOG_CHUNK ? lg : QUAD_MAX_LOG_CHUNK);
+        digest64* out = d_roots;
+        if (lg != step) {
+            void* b;
+            SHCHK(ensure_scratch(c, use_b ? SCR_DIG_B : SCR_DIG_A, (total >> step) * sizeof(digest64), &b));
+            use_b = !use_b;
+            out = (digest64*)b;
+        }
+        if (wide) HIPCHK(launch_node_subtree(cur, out, total >> step, step, c->stream));
+        else HIPCHK(launch_quad_reduce(cur, out, total, step, nullptr, 0, c->stream));
+        cur = out; lg -= step;
+    }
+    return SH_OK;
+}
+
+static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t N, const sh_fri_params* prm, sh_proofstream** streams,
+                                    uint8_t* roots_out, uint64_t* last_out, size_t* last_len) {
+    CTXCHK(c);
+    if (!d_cws || !streams || !roots_out || !last_out || !last_len) return sh_fail(SH_EINVAL, "fri_commit_batch: null pointer");
+    if (B == 0) return sh_fail(SH_EINVAL, "fri_commit_batch: empty batch");
+    for (size_t b = 0; b < B; ++b) if (!streams[b]) return sh_fail(SH_EINVAL, "fri_commit_batch: null proof stream");
+    if (!is_pow2(N)) return sh_fail(SH_EINVAL, "fri_commit_batch: N must be a power of two");
+    const uint32_t log_N = ilog2(N);
+    if (log_N > SH_MAX_LOG_N || ilog2(B) + log_N > 30) return sh_fail(SH_EINVAL, "fri_commit_batch: batch too large (B*N must be <= 2^30)");
+    fp off;
+    SHCHK(check_params(prm, &off));
+    const uint32_t R = sh_fri_num_rounds(N, prm->expansion, prm->num_colinearity_tests);
+    const fp* cur = d_cws;
+    size_t L = N;
+    if (R > 0) {
+        const fp* tw_inv;
+        SHCHK(get_twiddles(c, log_N, true, &tw_inv));
+        void *bufX = nullptr, *bufY = nullptr, *d_roots, *d_c0;
+        if (R > 1) SHCHK(ensure_scratch(c, SCR_IO_A, B * (N / 2) * sizeof(fp), &bufX));
+        if (R > 2) SHCHK(ensure_scratch(c, SCR_IO_B, B * (N / 4) * sizeof(fp), &bufY));
+        SHCHK(ensure_scratch(c, SCR_ROOTS, B * sizeof(digest64), &d_roots));
+        SHCHK(ensure_scratch(c, SCR_C0, B * sizeof(fp), &d_c0));
+        const size_t need = B * 64 + B * 16;
+        if (c->h_batch_bytes < need) {
+            if (c->h_batch) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->h_batch)); c->h_batch = nullptr; c->h_batch_bytes = 0; }
+            HIPCHK(hipHostMalloc((void**)&c->h_batch, need, hipHostMallocDefault));
+            c->h_batch_bytes = need;
+        }
+        uint8_t* h_roots = c->h_batch;
+        fp* h_c0 = reinterpret_cast<fp*>(c->h_batch + B * 64);
+        const fp inv2 = fp_inv(fp_make(2, 0, 0, 0));
+        fp off_inv = fp_inv(off);
+        auto leaf_k = [&](size_t len) {                 // per-lane subtree depth: fill the chip first, never cross a codeword
+            uint32_t K = leaf_subtree_k(ilog2(B * len));
+            const uint32_t lg = ilog2(len);
+            return K < lg ? K : lg;
+        };
+        {
+            const uint32_t K = leaf_k(L);
+            void* dig;
+            SHCHK(ensure_scratch(c, SCR_DIG_A, ((B * L) >> K) * sizeof(digest64), &dig));
+            HIPCHK(launch_leaf_subtree(cur, (digest64*)dig, (B * L) >> K, K, c->stream));
+            SHCHK(reduce_digests_batch(c, (const digest64*)dig, L >> K, B, (digest64*)d_roots));
+        }
+        for (uint32_t r = 0; r < R; ++r) {
+            HIPCHK(hipMemcpyAsync(h_roots, d_roots, B * 64, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            const bool want = r + 1 < R;
+            for (size_t b = 0; b < B; ++b) {
+                const uint8_t* root = h_roots + 64 * b;
+                memcpy(roots_out + 64 * (b * R + r), root, 64);
+                if (sh_proofstream_push_merkle_root(streams[b], root) != SH_OK) return SH_ECALLBACK;      // proof_stream.rs:25
+                if (want) {
+                    uint8_t dig[32];
+                    uint64_t aw[2];
+                    if (sh_proofstream_prover_fiat_shamir(streams[b], dig) != SH_OK) return SH_ECALLBACK; // proof_stream.rs:51
+                    SHCHK(sh_sample_field(dig, aw));                                                     // G3
+                    h_c0[b] = fp_to_mont(fp_mul(fp_mul(fp_load_host(aw), inv2), off_inv));
+                }
+            }
+            if (!want) break;
+            HIPCHK(hipMemcpyAsync(d_c0, h_c0, B * sizeof(fp), hipMemcpyHostToDevice, c->stream));
+            const size_t half = L / 2;
+            fp* next = (fp*)((r & 1) ? bufY : bufX);
+            const uint32_t K = leaf_k(half);
+            void* dig;
+            SHCHK(ensure_scratch(c, SCR_DIG_A, ((B * half) >> K) * sizeof(digest64), &dig));
+            HIPCHK(launch_fold_leaf_subtree(cur, L, B, (const fp*)d_c0, fp_zero(), tw_inv, log_N, r, next, (digest64*)dig, K, c->stream));
+            SHCHK(reduce_digests_batch(c, (const digest64*)dig, half >> K, B, (digest64*)d_roots));
+            cur = next; L = half;
+            off_inv = fp_mul(off_inv, off_inv);
+        }
+    }
+    HIPCHK(hipMemcpyAsync(last_out, cur, B * L * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *last_len = L;
+    for (size_t b = 0; b < B; ++b) SHCHK(sh_proofstream_push_codeword(streams[b], last_out + 2 * b * L, L));
     return SH_OK;
 }
 
@@ -601,6 +713,21 @@ int32_t sh_fri_commit_proofstream(sh_ctx* c, const uint64_t* codeword, size_t N,
     PsCbState st{ps};
     SHCHK(sh_fri_commit(c, codeword, N, params, ps_callback, &st, roots_out, last_codeword_out, last_len));
     return sh_proofstream_push_codeword(ps, last_codeword_out, *last_len);
+}
+
+int32_t sh_dev_fri_commit_batch(sh_ctx* c, const uint64_t* d_codewords, size_t B, size_t N, const sh_fri_params* params, sh_proofstream** streams,
+                                uint8_t* roots_out, uint64_t* last_codewords_out, size_t* last_len) {
+    return fri_commit_batch_dev(c, (const fp*)d_codewords, B, N, params, streams, roots_out, last_codewords_out, last_len);
+}
+int32_t sh_fri_commit_batch(sh_ctx* c, const uint64_t* codewords, size_t B, size_t N, const sh_fri_params* params, sh_proofstream** streams,
+                            uint8_t* roots_out, uint64_t* last_codewords_out, size_t* last_len) {
+    CTXCHK(c);
+    if (!codewords) return sh_fail(SH_EINVAL, "sh_fri_commit_batch: null pointer");
+    if (B == 0 || !is_pow2(N) || ilog2(N) > SH_MAX_LOG_N || ilog2(B) + ilog2(N) > 30) return sh_fail(SH_EINVAL, "sh_fri_commit_batch: bad batch shape");
+    void* d;
+    SHCHK(ensure_scratch(c, SCR_IO_C, B * N * 16, &d));
+    HIPCHK(hipMemcpyAsync(d, codewords, B * N * 16, hipMemcpyHostToDevice, c->stream));
+    return fri_commit_batch_dev(c, (const fp*)d, B, N, params, streams, roots_out, last_codewords_out, last_len);
 }
 
 // ------------------------------------------------------------------ host-only scalar helpers

@@ -152,17 +152,23 @@ __device__ __forceinline__ fp load_tw(const fp* __restrict__ tw, uint32_t log_n,
 }
 
 // Fused FRI round: fold, write the folded codeword, and hash it into 2^K-leaf subtree digests.
-__global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const fp* __restrict__ cw, size_t half, fp c0_mont,
-                                                           const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
+// Batched form: B codewords of length 2*half back to back; lane i owns outputs [i<<K, (i+1)<<K) of the
+// concatenated folded codewords (2^K <= half, so a lane never straddles two codewords).  The per-codeword
+// constant c0 = alpha/(2*offset) comes from `c0_arr[b]` (device, Montgomery form) or, when null, `c0_single`.
+__global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const fp* __restrict__ cw, uint32_t log_half, const fp* __restrict__ c0_arr,
+                                                           fp c0_single, const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
                                                            fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out, uint32_t K) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
-    const size_t j0 = i << K;
+    const size_t j0 = i << K, half = (size_t)1 << log_half;
+    const size_t b = j0 >> log_half, w0 = j0 & (half - 1);
+    const fp c0_mont = c0_arr ? c0_arr[b] : c0_single;
+    const fp* lo = cw + (b << (log_half + 1)) + w0;
+    const fp* hi = lo + half;
     digest64 d = subtree_reduce(K, [&](uint32_t q) {
-        const size_t j = j0 + q;
-        fp t = mont_mul(load_tw(tw_inv, log_n_table, j << tw_shift), c0_mont);
-        fp v = fold_one(cw[j], cw[half + j], t);
-        out[j] = v;
+        fp t = mont_mul(load_tw(tw_inv, log_n_table, (w0 + q) << tw_shift), c0_mont);
+        fp v = fold_one(lo[q], hi[q], t);
+        out[j0 + q] = v;
         return b2b_leaf(fp_lo64(v), fp_hi64(v));
     });
     store_digest(digests + i, d);
@@ -202,12 +208,14 @@ hipError_t launch_fri_fold(const fp* cw, size_t L, fp c0_mont, fp omega_inv, fp*
     hipLaunchKernelGGL(k_fri_fold, dim3(grid_for(threads, 256)), dim3(256), 0, s, cw, half, c0_mont, omega_inv, out);
     return hipGetLastError();
 }
-hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, fp c0_mont, const fp* tw_inv, uint32_t log_n_table,
+hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* c0_arr, fp c0_single, const fp* tw_inv, uint32_t log_n_table,
                                     uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s) {
     const size_t half = L / 2;
-    if (!half || K > SUBTREE_KMAX || (half >> K) == 0) return hipErrorInvalidValue;
-    const size_t n_out = half >> K;
-    hipLaunchKernelGGL(k_fold_leaf_subtree, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, half, c0_mont, tw_inv,
+    if (!half || (half & (half - 1)) || !B || K > SUBTREE_KMAX || (half >> K) == 0) return hipErrorInvalidValue;
+    uint32_t log_half = 0;
+    while (((size_t)1 << log_half) < half) ++log_half;
+    const size_t n_out = (B * half) >> K;
+    hipLaunchKernelGGL(k_fold_leaf_subtree, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
                        log_n_table, tw_shift, out, digests, n_out, K);
     return hipGetLastError();
 }

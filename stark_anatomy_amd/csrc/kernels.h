@@ -47,7 +47,9 @@ hipError_t launch_quad_reduce(const digest64* in, digest64* out, size_t n_in, ui
 // ---- hash_kernels.hip (FRI round) ----
 // generic split-and-fold (any omega): out[i] = (a+b)/2 + c0·omega^-i·(a-b),  c0 = alpha/(2·offset)
 hipError_t launch_fri_fold(const fp* cw, size_t L, fp c0_mont, fp omega_inv, fp* out, hipStream_t s);
-// fused round: fold cw (length L) into out (length L/2) with twiddles w_N^-(i << tw_shift) from the
-// inverse table of the top-level domain, and emit the 2^K-leaf subtree digests of the folded codeword.
-hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, fp c0_mont, const fp* tw_inv, uint32_t log_n_table,
+// fused round for B codewords of length L stored back to back: fold each into length L/2 (also back to back in
+// `out`) with twiddles w_N^-(i << tw_shift) from the inverse table of the top-level domain, and emit the 2^K-leaf
+// subtree digests of the folded codewords.  c0 = alpha/(2*offset) in Montgomery form: per codeword from the device
+// array `c0_arr`, or `c0_single` when c0_arr is null.
+hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* c0_arr, fp c0_single, const fp* tw_inv, uint32_t log_n_table,
                                     uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s);

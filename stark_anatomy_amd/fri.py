@@ -84,6 +84,27 @@ class Fri:
         check(rc)
         return [MerkleHash(roots[i].tobytes()) for i in range(R)], last[:last_len.value]
 
+    def commit_batch(self, codewords, proof_streams):
+        """B independent commits in lock step (sh_fri_commit_batch).  `codewords`: host array of shape (B, N, 2) /
+        list of B codewords, or a device buffer holding B*N elements back to back; `proof_streams`: B ProofStreams.
+        Returns (roots[b][r], last_codewords (B, last_len, 2))."""
+        N, R, B = self.domain_length, self.num_rounds(), len(proof_streams)
+        roots = np.zeros((B, max(R, 1), 64), dtype=np.uint8)
+        L_last = N >> max(R - 1, 0)
+        last = np.empty((B, L_last, 2), dtype=np.uint64)
+        last_len = C.c_size_t(0)
+        p = self._params()
+        handles = (_lib.ps_t * B)(*[ps.handle for ps in proof_streams])
+        if isinstance(codewords, (list, tuple, np.ndarray)):
+            cw = np.ascontiguousarray(np.stack([elems_to_array(x) for x in codewords]) if not isinstance(codewords, np.ndarray) else codewords,
+                                      dtype=np.uint64).reshape(B * N, 2)
+            rc = lib.sh_fri_commit_batch(self.ctx.handle, _u64p(cw), B, N, C.byref(p), handles, _u8p(roots), _u64p(last), C.byref(last_len))
+        else:
+            rc = lib.sh_dev_fri_commit_batch(self.ctx.handle, device_ptr(codewords), B, N, C.byref(p), handles, _u8p(roots), _u64p(last), C.byref(last_len))
+        check(rc)
+        assert last_len.value == L_last
+        return [[MerkleHash(roots[b, r].tobytes()) for r in range(R)] for b in range(B)], last
+
     def commit_with_callback(self, codeword, callback):
         """Low-level form: `callback(round, root_bytes, want_alpha) -> int|None` owns the transcript
         (sh_fri_commit / sh_transcript_cb)."""

@@ -348,3 +348,28 @@ def test_fri_commit_2_24_properties(ctx):
             assert root.tobytes() == roots[r + 1].as_bytes()
     assert (cur.download(np.uint64, (L, 2)) == last).all()
     cur.free(); d.free()
+
+
+# ------------------------------------------------------------------ batched commits (BASELINE config 4)
+@pytest.mark.parametrize("B,log_n", [(1, 10), (3, 7), (8, 14), (128, 14), (5, 1), (2, 18)])
+def test_fri_commit_batch_vs_oracle(ctx, B, log_n):
+    """B lock-step commits == B separate oracle commits: roots, last codewords and every proof stream's bytes."""
+    N = 1 << log_n
+    cws = np.stack([co.splitmix_elems(1000 + b, N) for b in range(B)])
+    t = 17 if log_n > 1 else 0
+    exp = 4 if log_n > 1 else 1
+    fri = sa.Fri(G, None, N, exp, t, ctx=ctx)
+    streams = [sa.ProofStream() for _ in range(B)]
+    roots, last = fri.commit_batch(cws, streams)
+    check = range(B) if B <= 8 else (0, 1, 63, B - 1)
+    for b in check:
+        oroots, _, olast, ops = co.fri_commit(cws[b], exp, t, G)
+        assert [r.as_bytes() for r in roots[b]] == oroots
+        assert (last[b] == olast).all()
+        assert streams[b].serialize() == ops.serialize()
+    # device-resident batch gives the same bytes
+    d = ctx.alloc(B * N * 16).upload(cws.reshape(B * N, 2))
+    streams2 = [sa.ProofStream() for _ in range(B)]
+    roots2, last2 = fri.commit_batch(d, streams2)
+    assert (last2 == last).all() and all(a.serialize() == b_.serialize() for a, b_ in zip(streams, streams2))
+    d.free()
