@@ -6,9 +6,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <map>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/stark_hip.h"
 #include "host_internal.h"
@@ -458,23 +461,45 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
             HIPCHK(launch_leaf_subtree(cur, (digest64*)dig, (B * L) >> K, K, c->stream));
             SHCHK(reduce_digests_batch(c, (const digest64*)dig, L >> K, B, (digest64*)d_roots));
         }
+        const bool dbg = getenv("STARK_HIP_DEBUG") != nullptr;
+        double t_wait = 0, t_host = 0;
+        auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         for (uint32_t r = 0; r < R; ++r) {
+            const double t0 = now();
             HIPCHK(hipMemcpyAsync(h_roots, d_roots, B * 64, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
+            const double t1 = now();
+            t_wait += t1 - t0;
             const bool want = r + 1 < R;
-            for (size_t b = 0; b < B; ++b) {
-                const uint8_t* root = h_roots + 64 * b;
-                memcpy(roots_out + 64 * (b * R + r), root, 64);
-                if (sh_proofstream_push_merkle_root(streams[b], root) != SH_OK) return SH_ECALLBACK;      // proof_stream.rs:25
-                if (want) {
-                    uint8_t dig[32];
-                    uint64_t aw[2];
-                    if (sh_proofstream_prover_fiat_shamir(streams[b], dig) != SH_OK) return SH_ECALLBACK; // proof_stream.rs:51
-                    SHCHK(sh_sample_field(dig, aw));                                                     // G3
-                    h_c0[b] = fp_to_mont(fp_mul(fp_mul(fp_load_host(aw), inv2), off_inv));
+            std::atomic<int> failed{0};
+            auto per_codeword = [&](size_t b0, size_t b1) {          // transcripts are independent: one ProofStream per codeword
+                for (size_t b = b0; b < b1; ++b) {
+                    const uint8_t* root = h_roots + 64 * b;
+                    memcpy(roots_out + 64 * (b * R + r), root, 64);
+                    if (sh_proofstream_push_merkle_root(streams[b], root) != SH_OK) { failed = 1; return; }      // proof_stream.rs:25
+                    if (want) {
+                        uint8_t dig[32];
+                        uint64_t aw[2];
+                        if (sh_proofstream_prover_fiat_shamir(streams[b], dig) != SH_OK) { failed = 1; return; } // proof_stream.rs:51
+                        if (sh_sample_field(dig, aw) != SH_OK) { failed = 1; return; }                           // G3
+                        h_c0[b] = fp_to_mont(fp_mul(fp_mul(fp_load_host(aw), inv2), off_inv));
+                    }
                 }
+            };
+            unsigned T = std::thread::hardware_concurrency();
+            if (T > 16) T = 16;
+            if (T > B / 32) T = (unsigned)(B / 32);
+            if (T <= 1) per_codeword(0, B);
+            else {
+                std::vector<std::thread> th;
+                const size_t chunk = (B + T - 1) / T;
+                for (unsigned t = 1; t < T; ++t) th.emplace_back(per_codeword, t * chunk < B ? t * chunk : B, (t + 1) * chunk < B ? (t + 1) * chunk : B);
+                per_codeword(0, chunk < B ? chunk : B);
+                for (auto& x : th) x.join();
             }
-            if (!want) break;
+            if (failed) return sh_fail(SH_ECALLBACK, "fri_commit_batch: transcript update failed");
+            t_host += now() - t1;
+            if (!want) { if (dbg) fprintf(stderr, "[stark_hip] batch B=%zu N=%zu: wait %.0f us, host transcript %.0f us over %u rounds\n", B, N, t_wait, t_host, R); break; }
             HIPCHK(hipMemcpyAsync(d_c0, h_c0, B * sizeof(fp), hipMemcpyHostToDevice, c->stream));
             const size_t half = L / 2;
             fp* next = (fp*)((r & 1) ? bufY : bufX);
@@ -490,7 +515,22 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
     HIPCHK(hipMemcpyAsync(last_out, cur, B * L * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *last_len = L;
-    for (size_t b = 0; b < B; ++b) SHCHK(sh_proofstream_push_codeword(streams[b], last_out + 2 * b * L, L));
+    {
+        std::atomic<int> failed{0};
+        auto push = [&](size_t b0, size_t b1) { for (size_t b = b0; b < b1; ++b) if (sh_proofstream_push_codeword(streams[b], last_out + 2 * b * L, L) != SH_OK) failed = 1; };
+        unsigned T = std::thread::hardware_concurrency();
+        if (T > 16) T = 16;
+        if (T > B / 16) T = (unsigned)(B / 16);
+        if (T <= 1) push(0, B);
+        else {
+            std::vector<std::thread> th;
+            const size_t chunk = (B + T - 1) / T;
+            for (unsigned t = 1; t < T; ++t) th.emplace_back(push, t * chunk < B ? t * chunk : B, (t + 1) * chunk < B ? (t + 1) * chunk : B);
+            push(0, chunk < B ? chunk : B);
+            for (auto& x : th) x.join();
+        }
+        if (failed) return sh_fail(SH_ECALLBACK, "fri_commit_batch: pushing the last codeword failed");
+    }
     return SH_OK;
 }
 

@@ -4,6 +4,7 @@
 // has it; what matters is that the BYTES are identical to serde_json's compact output.
 //
 // This is product code (part of libstark_hip.so).  It shares nothing with oracle/.
+#include <immintrin.h>
 #include <stdint.h>
 #include <string.h>
 #include <new>
@@ -24,6 +25,40 @@ const uint32_t K256[64] = {
     0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
 inline uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 
+// One block with the x86 SHA extensions (same FIPS 180-4 function; selected at run time when the CPU has them).
+__attribute__((target("sha,sse4.1,ssse3"))) void sha256_block_shani(uint32_t st[8], const uint8_t* p) {
+    const __m128i MASK = _mm_set_epi64x(0x0c0d0e0f08090a0bLL, 0x0405060700010203LL);
+    __m128i tmp = _mm_loadu_si128((const __m128i*)&st[0]);            // DCBA
+    __m128i s1 = _mm_loadu_si128((const __m128i*)&st[4]);             // HGFE
+    tmp = _mm_shuffle_epi32(tmp, 0xB1);                               // CDAB
+    s1 = _mm_shuffle_epi32(s1, 0x1B);                                 // EFGH
+    __m128i s0 = _mm_alignr_epi8(tmp, s1, 8);                         // ABEF
+    s1 = _mm_blend_epi16(s1, tmp, 0xF0);                              // CDGH
+    const __m128i save0 = s0, save1 = s1;
+    __m128i m[4];
+    for (int i = 0; i < 16; ++i) {                                    // 16 groups of 4 rounds
+        if (i < 4) m[i] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 16 * i)), MASK);
+        else {
+            __m128i t = _mm_sha256msg1_epu32(m[i & 3], m[(i + 1) & 3]);
+            t = _mm_add_epi32(t, _mm_alignr_epi8(m[(i + 3) & 3], m[(i + 2) & 3], 4));
+            m[i & 3] = _mm_sha256msg2_epu32(t, m[(i + 3) & 3]);
+        }
+        __m128i msg = _mm_add_epi32(m[i & 3], _mm_loadu_si128((const __m128i*)&K256[4 * i]));
+        s1 = _mm_sha256rnds2_epu32(s1, s0, msg);
+        msg = _mm_shuffle_epi32(msg, 0x0E);
+        s0 = _mm_sha256rnds2_epu32(s0, s1, msg);
+    }
+    s0 = _mm_add_epi32(s0, save0);
+    s1 = _mm_add_epi32(s1, save1);
+    tmp = _mm_shuffle_epi32(s0, 0x1B);                                // FEBA
+    s1 = _mm_shuffle_epi32(s1, 0xB1);                                 // DCHG
+    s0 = _mm_blend_epi16(tmp, s1, 0xF0);                              // DCBA
+    s1 = _mm_alignr_epi8(s1, tmp, 8);                                 // HGFE
+    _mm_storeu_si128((__m128i*)&st[0], s0);
+    _mm_storeu_si128((__m128i*)&st[4], s1);
+}
+const bool HAVE_SHANI = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
+
 struct Sha256 {
     uint32_t st[8];
     uint8_t buf[64];
@@ -34,6 +69,7 @@ struct Sha256 {
         memcpy(st, init, sizeof st);
     }
     void block(const uint8_t* p) {
+        if (HAVE_SHANI) { sha256_block_shani(st, p); return; }
         uint32_t w[64];
         for (int i = 0; i < 16; ++i) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
         for (int i = 16; i < 64; ++i) {
@@ -137,15 +173,30 @@ struct Sha256Ctx { Sha256 h; };
 sh_proofstream::~sh_proofstream() { delete running; }
 
 namespace {
-void append_u64_dec(std::string& s, uint64_t v) {
-    char tmp[24]; int n = 0;
-    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) s.push_back(tmp[--n]);
+// decimal formatting into a caller-provided buffer (no per-character std::string growth); returns chars written
+const char DIGIT_PAIRS[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960"
+    "616263646566676869707172737475767778798081828384858687888990919293949596979899";
+inline size_t put_u64_dec(char* out, uint64_t v) {
+    char tmp[20]; int n = 0;
+    while (v >= 100) { const unsigned r = (unsigned)(v % 100); v /= 100; tmp[n++] = DIGIT_PAIRS[2 * r + 1]; tmp[n++] = DIGIT_PAIRS[2 * r]; }
+    if (v >= 10) { tmp[n++] = DIGIT_PAIRS[2 * v + 1]; tmp[n++] = DIGIT_PAIRS[2 * v]; }
+    else tmp[n++] = (char)('0' + v);
+    for (int i = 0; i < n; ++i) out[i] = tmp[n - 1 - i];
+    return (size_t)n;
 }
-void append_u128_dec(std::string& s, unsigned __int128 v) {      // serde_json writes u128 as a bare decimal integer
-    char tmp[40]; int n = 0;
-    do { tmp[n++] = (char)('0' + (int)(v % 10)); v /= 10; } while (v);
-    while (n) s.push_back(tmp[--n]);
+inline size_t put_u64_dec_padded19(char* out, uint64_t v) {                 // exactly 19 digits, zero padded
+    for (int i = 18; i >= 0; --i) { out[i] = (char)('0' + v % 10); v /= 10; }
+    return 19;
+}
+inline size_t put_u128_dec(char* out, unsigned __int128 v) {               // serde_json writes u128 as a bare decimal integer
+    const uint64_t E19 = 10000000000000000000ULL;                          // base-10^19 limbs: two 128-bit divisions at most
+    if ((uint64_t)(v >> 64) == 0) return put_u64_dec(out, (uint64_t)v);
+    const uint64_t l0 = (uint64_t)(v % E19); v /= E19;
+    size_t n;
+    if ((uint64_t)(v >> 64) == 0 && (uint64_t)v < E19) n = put_u64_dec(out, (uint64_t)v);
+    else { const uint64_t l1 = (uint64_t)(v % E19); v /= E19; n = put_u64_dec(out, (uint64_t)v); n += put_u64_dec_padded19(out + n, l1); }
+    return n + put_u64_dec_padded19(out + n, l0);
 }
 std::string serialize_items(const std::vector<std::string>& items, size_t count) {   // serialize_inner, proof_stream.rs:67-69
     size_t need = 2;
@@ -271,21 +322,26 @@ int32_t sh_proofstream_push_json(sh_proofstream* ps, const uint8_t* json, size_t
 }
 int32_t sh_proofstream_push_merkle_root(sh_proofstream* ps, const uint8_t root[64]) {         // merkle.rs:9-13 shape
     if (!ps || !root) return sh_fail(SH_EINVAL, "sh_proofstream_push_merkle_root: null pointer");
-    std::string s = "{\"MerkleRoot\":{\"inner\":[";
-    for (int i = 0; i < 64; ++i) { if (i) s.push_back(','); append_u64_dec(s, root[i]); }
-    s += "]}}";
-    ps->items.push_back(std::move(s));
+    char buf[24 + 64 * 4 + 4];
+    size_t o = 24;
+    memcpy(buf, "{\"MerkleRoot\":{\"inner\":[", 24);
+    for (int i = 0; i < 64; ++i) { if (i) buf[o++] = ','; o += put_u64_dec(buf + o, root[i]); }
+    memcpy(buf + o, "]}}", 3);
+    ps->items.emplace_back(buf, o + 3);
     return SH_OK;
 }
 int32_t sh_proofstream_push_codeword(sh_proofstream* ps, const uint64_t* elems, size_t n) {
     if (!ps || (!elems && n)) return sh_fail(SH_EINVAL, "sh_proofstream_push_codeword: null pointer");
-    std::string s = "{\"Codeword\":[";
-    s.reserve(16 + n * 40);
+    std::string s(13 + n * 40 + 2, '\0');
+    char* buf = &s[0];
+    size_t o = 13;
+    memcpy(buf, "{\"Codeword\":[", 13);
     for (size_t i = 0; i < n; ++i) {
-        if (i) s.push_back(',');
-        append_u128_dec(s, ((unsigned __int128)elems[2 * i + 1] << 64) | elems[2 * i]);
+        if (i) buf[o++] = ',';
+        o += put_u128_dec(buf + o, ((unsigned __int128)elems[2 * i + 1] << 64) | elems[2 * i]);
     }
-    s += "]}";
+    buf[o++] = ']'; buf[o++] = '}';
+    s.resize(o);
     ps->items.push_back(std::move(s));
     return SH_OK;
 }

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Time sh_dev_fri_commit_batch for B x 2^log_n, with the ProofStream objects created outside the timed call."""
+import ctypes as C, sys, time
+import numpy as np
+import stark_anatomy_amd as sa
+from stark_anatomy_amd import _lib
+from stark_anatomy_amd.context import _u8p, _u64p
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+log_n = int(sys.argv[2]) if len(sys.argv) > 2 else 14
+n = 1 << log_n
+ctx = sa.Context(0); H = ctx.handle
+raw = np.frombuffer(np.random.default_rng(1).bytes(16 * B * n), dtype=np.uint64).reshape(-1, 2)
+red = np.empty_like(raw); _lib.check(_lib.lib.sh_fp_new(H, _u64p(np.ascontiguousarray(raw)), _u64p(red), B * n))
+d = ctx.alloc(B * n * 16).upload(red)
+p = _lib.FriParams(); p.expansion, p.num_colinearity_tests = 4, 17
+p.offset[0], p.offset[1] = sa.GENERATOR & 0xFFFFFFFFFFFFFFFF, sa.GENERATOR >> 64
+R = int(_lib.lib.sh_fri_num_rounds(n, 4, 17))
+roots = np.zeros((B, R, 64), dtype=np.uint8); last = np.empty((B, n >> (R - 1), 2), dtype=np.uint64); ll = C.c_size_t(0)
+for it in range(6):
+    pss = [sa.ProofStream() for _ in range(B)]
+    handles = (_lib.ps_t * B)(*[q.handle for q in pss])
+    t0 = time.perf_counter()
+    _lib.check(_lib.lib.sh_dev_fri_commit_batch(H, d.ptr, B, n, C.byref(p), handles, _u8p(roots), _u64p(last), C.byref(ll)))
+    dt = time.perf_counter() - t0
+    print(f"B={B} N=2^{log_n}: {dt*1e3:.3f} ms  {B*n/dt/1e6:.1f} M elems/s", flush=True)
