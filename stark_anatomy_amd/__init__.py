@@ -11,6 +11,7 @@ Everything computes in hand-written HIP kernels through libstark_hip.so (C ABI: 
 There is no CPU fallback: importing this package without the built library raises ImportError.
 """
 from . import _lib  # noqa: F401  (fails loudly if the HIP extension is missing)
+from . import dist  # noqa: F401  (sharding helpers; imports torch lazily)
 from ._lib import StarkHipError
 from .context import Context, DeviceBuffer, array_to_ints, default_context, elems_to_array
 from .field import GENERATOR, ONE, PRIME, ZERO, FieldElement, FieldVector, generator, root_of_unity

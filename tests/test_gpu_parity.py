@@ -373,3 +373,14 @@ def test_fri_commit_batch_vs_oracle(ctx, B, log_n):
     roots2, last2 = fri.commit_batch(d, streams2)
     assert (last2 == last).all() and all(a.serialize() == b_.serialize() for a, b_ in zip(streams, streams2))
     d.free()
+
+
+def test_sharded_engine_single_rank(ctx):
+    """the product engine behind stark_anatomy_amd.dist (world size 1): same bytes as the oracle per codeword."""
+    from stark_anatomy_amd.dist import commit_batch_sharded, gpu_engine
+    B, N = 6, 1 << 9
+    cws = np.stack([co.splitmix_elems(500 + b, N) for b in range(B)])
+    roots, last, streams = commit_batch_sharded(cws, gpu_engine(N, ctx=ctx))
+    for b in range(B):
+        r, _, l, ps = co.fri_commit(cws[b], 4, 17, G)
+        assert roots[b].tobytes() == b"".join(r) and (last[b] == l).all() and streams[b] == ps.serialize()
