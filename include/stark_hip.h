@@ -83,6 +83,15 @@ int32_t sh_dev_fp_inv(sh_ctx* ctx, const uint64_t* d_a, uint64_t* d_out, size_t 
 #define SH_MAX_LOG_N 28
 int32_t sh_ntt(sh_ctx* ctx, uint64_t* data, uint32_t log_n, int32_t inverse);
 int32_t sh_dev_ntt(sh_ctx* ctx, uint64_t* d_data, uint32_t log_n, int32_t inverse);
+/* `batch` independent transforms of 2^log_n elements each, stored back to back (batch·2^log_n <= 2^(SH_MAX_LOG_N+2)).
+ * Together with sh_*_twiddle_scale these are the local steps of the multi-GPU four-step NTT
+ * (BASELINE.json C5; host side in stark_anatomy_amd/dist_ntt.py); no reference counterpart. */
+int32_t sh_ntt_batch(sh_ctx* ctx, uint64_t* data, size_t batch, uint32_t log_n, int32_t inverse);
+int32_t sh_dev_ntt_batch(sh_ctx* ctx, uint64_t* d_data, size_t batch, uint32_t log_n, int32_t inverse);
+/* data[r][c] *= w^((row0+r)·(col0+c)) over a rows x 2^log_cols row-major block, w = g^(2^119 / 2^log_n)
+ * (w^-1 when inverse): the twiddle between the column and the row transforms of a four-step NTT of 2^log_n points. */
+int32_t sh_twiddle_scale(sh_ctx* ctx, uint64_t* data, size_t rows, uint32_t log_cols, uint64_t row0, uint64_t col0, uint32_t log_n, int32_t inverse);
+int32_t sh_dev_twiddle_scale(sh_ctx* ctx, uint64_t* d_data, size_t rows, uint32_t log_cols, uint64_t row0, uint64_t col0, uint32_t log_n, int32_t inverse);
 /* out[i] = f(offset·w_N^i), i in [0, n << log_expansion), f = sum_j coeffs[j] X^j. */
 int32_t sh_coset_lde(sh_ctx* ctx, const uint64_t* coeffs, uint32_t log_n, uint32_t log_expansion,
                      const uint64_t offset[2], uint64_t* out);
@@ -116,6 +125,12 @@ int32_t sh_fri_fold(sh_ctx* ctx, const uint64_t* cw, size_t L, const uint64_t al
                     const uint64_t offset[2], const uint64_t omega[2], uint64_t* out);
 int32_t sh_dev_fri_fold(sh_ctx* ctx, const uint64_t* d_cw, size_t L, const uint64_t alpha[2],
                         const uint64_t offset[2], const uint64_t omega[2], uint64_t* d_out);
+/* The same fold for the slice i in [i0, i0+count) of the folded codeword: d_lo[k] = cw[i0+k], d_hi[k] = cw[L/2+i0+k].
+ * One rank's share of a round when a single codeword is spread over GPUs (dist_ntt.py). */
+int32_t sh_dev_fri_fold_range(sh_ctx* ctx, const uint64_t* d_lo, const uint64_t* d_hi, size_t count, uint64_t i0,
+                              const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], uint64_t* d_out);
+/* d_data[i] *= base^(j0+i), i < count: the coset pre-scale (G7) of the slice [j0, j0+count) of a coefficient vector. */
+int32_t sh_dev_scale_powers(sh_ctx* ctx, uint64_t* d_data, size_t count, uint64_t j0, const uint64_t base[2]);
 
 /* ---------------- FRI commit driver ----------------
  * for r in 0..R: root_r = merkle(leafhash(cw_r)); cb(root_r) -> alpha_r; cw_{r+1} = fold(cw_r).

@@ -64,6 +64,10 @@ _PROTOS = {
     "sh_dev_fp_inv": (C.c_int32, [ctx_t, C.c_void_p, C.c_void_p, C.c_size_t]),
     "sh_ntt": (C.c_int32, [ctx_t, u64p, C.c_uint32, C.c_int32]),
     "sh_dev_ntt": (C.c_int32, [ctx_t, C.c_void_p, C.c_uint32, C.c_int32]),
+    "sh_ntt_batch": (C.c_int32, [ctx_t, u64p, C.c_size_t, C.c_uint32, C.c_int32]),
+    "sh_dev_ntt_batch": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int32]),
+    "sh_twiddle_scale": (C.c_int32, [ctx_t, u64p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32]),
+    "sh_dev_twiddle_scale": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32]),
     "sh_coset_lde": (C.c_int32, [ctx_t, u64p, C.c_uint32, C.c_uint32, u64p, u64p]),
     "sh_dev_coset_lde": (C.c_int32, [ctx_t, C.c_void_p, C.c_uint32, C.c_uint32, u64p, C.c_void_p]),
     "sh_merkle_commit": (C.c_int32, [ctx_t, u8p, C.c_size_t, u8p]),
@@ -76,6 +80,8 @@ _PROTOS = {
     "sh_merkle_open": (C.c_int32, [ctx_t, u8p, C.c_size_t, C.c_size_t, u8p, szp]),
     "sh_fri_fold": (C.c_int32, [ctx_t, u64p, C.c_size_t, u64p, u64p, u64p, u64p]),
     "sh_dev_fri_fold": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, u64p, u64p, u64p, C.c_void_p]),
+    "sh_dev_fri_fold_range": (C.c_int32, [ctx_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, u64p, u64p, u64p, C.c_void_p]),
+    "sh_dev_scale_powers": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_uint64, u64p]),
     "sh_fri_num_rounds": (C.c_uint32, [C.c_size_t, C.c_uint32, C.c_uint32]),
     "sh_fri_commit": (C.c_int32, [ctx_t, u64p, C.c_size_t, C.POINTER(FriParams), TRANSCRIPT_CB, C.c_void_p, u8p, u64p, szp]),
     "sh_dev_fri_commit": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.POINTER(FriParams), TRANSCRIPT_CB, C.c_void_p, u8p, u64p, szp]),

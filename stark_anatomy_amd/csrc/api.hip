@@ -235,9 +235,11 @@ static int32_t host_fp_op(sh_ctx* c, int op, const uint64_t* a, const uint64_t* 
 }
 
 // ------------------------------------------------------------------ NTT / LDE
-static int32_t dev_ntt(sh_ctx* c, fp* d_data, uint32_t log_n, bool inverse) {
+static int32_t dev_ntt(sh_ctx* c, fp* d_data, uint32_t log_n, bool inverse, size_t batch = 1) {
     if (log_n > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "ntt: log_n %u > %d", log_n, SH_MAX_LOG_N);
-    const size_t n = (size_t)1 << log_n;
+    if (batch == 0) return SH_OK;
+    if (batch > ((size_t)1 << (SH_MAX_LOG_N + 2 - log_n))) return sh_failf(SH_EINVAL, "ntt: batch %zu x 2^%u exceeds 2^%d elements", batch, log_n, SH_MAX_LOG_N + 2);
+    const size_t n = ((size_t)1 << log_n) * batch;
     const fp* tw;
     SHCHK(get_twiddles(c, log_n, inverse, &tw));
     void* scratch;
@@ -245,8 +247,8 @@ static int32_t dev_ntt(sh_ctx* c, fp* d_data, uint32_t log_n, bool inverse) {
     NttPlan plan;
     ntt_make_plan(log_n, &plan);
     fp scale = fp_mont_one();
-    if (inverse) scale = fp_to_mont(fp_inv(fp_from_u64x2((uint64_t)n, 0)));
-    HIPCHK(launch_ntt(plan, d_data, (fp*)scratch, tw, scale, inverse, c->stream));
+    if (inverse) scale = fp_to_mont(fp_inv(fp_from_u64x2((uint64_t)1 << log_n, 0)));
+    HIPCHK(launch_ntt(plan, d_data, (fp*)scratch, tw, scale, inverse, batch, c->stream));
     return SH_OK;
 }
 
@@ -565,6 +567,51 @@ int32_t sh_dev_ntt(sh_ctx* c, uint64_t* d_data, uint32_t log_n, int32_t inverse)
     if (!d_data) return sh_fail(SH_EINVAL, "sh_dev_ntt: null pointer");
     return dev_ntt(c, (fp*)d_data, log_n, inverse != 0);
 }
+int32_t sh_dev_ntt_batch(sh_ctx* c, uint64_t* d_data, size_t batch, uint32_t log_n, int32_t inverse) {
+    CTXCHK(c);
+    if (!d_data && batch) return sh_fail(SH_EINVAL, "sh_dev_ntt_batch: null pointer");
+    return dev_ntt(c, (fp*)d_data, log_n, inverse != 0, batch);
+}
+int32_t sh_ntt_batch(sh_ctx* c, uint64_t* data, size_t batch, uint32_t log_n, int32_t inverse) {
+    CTXCHK(c);
+    if (!batch) return SH_OK;
+    if (!data) return sh_fail(SH_EINVAL, "sh_ntt_batch: null pointer");
+    if (log_n > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "sh_ntt_batch: log_n %u > %d", log_n, SH_MAX_LOG_N);
+    if (batch > ((size_t)1 << (SH_MAX_LOG_N + 2 - log_n))) return sh_failf(SH_EINVAL, "sh_ntt_batch: batch %zu x 2^%u exceeds 2^%d elements", batch, log_n, SH_MAX_LOG_N + 2);
+    const size_t bytes = (batch << log_n) * 16;
+    void* d;
+    SHCHK(ensure_scratch(c, SCR_IO_A, bytes, &d));
+    HIPCHK(hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, c->stream));
+    SHCHK(dev_ntt(c, (fp*)d, log_n, inverse != 0, batch));
+    HIPCHK(hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SH_OK;
+}
+int32_t sh_dev_twiddle_scale(sh_ctx* c, uint64_t* d_data, size_t rows, uint32_t log_cols, uint64_t row0, uint64_t col0, uint32_t log_n, int32_t inverse) {
+    CTXCHK(c);
+    if (!rows) return SH_OK;
+    if (!d_data) return sh_fail(SH_EINVAL, "sh_dev_twiddle_scale: null pointer");
+    if (log_n > SH_MAX_LOG_N || log_cols > log_n) return sh_failf(SH_EINVAL, "sh_dev_twiddle_scale: log_cols %u, log_n %u out of range", log_cols, log_n);
+    if ((row0 + rows) > ((uint64_t)1 << 32) || (col0 >> 32)) return sh_fail(SH_EINVAL, "sh_dev_twiddle_scale: row/column index beyond 2^32");
+    const fp* tw;
+    SHCHK(get_twiddles(c, log_n, inverse != 0, &tw));
+    HIPCHK(launch_twiddle_scale((fp*)d_data, rows, log_cols, row0, col0, tw, log_n, c->stream));
+    return SH_OK;
+}
+int32_t sh_twiddle_scale(sh_ctx* c, uint64_t* data, size_t rows, uint32_t log_cols, uint64_t row0, uint64_t col0, uint32_t log_n, int32_t inverse) {
+    CTXCHK(c);
+    if (!rows) return SH_OK;
+    if (!data) return sh_fail(SH_EINVAL, "sh_twiddle_scale: null pointer");
+    if (log_cols > SH_MAX_LOG_N || rows > ((size_t)1 << (SH_MAX_LOG_N + 2 - log_cols))) return sh_fail(SH_EINVAL, "sh_twiddle_scale: block too large");
+    const size_t bytes = (rows << log_cols) * 16;
+    void* d;
+    SHCHK(ensure_scratch(c, SCR_IO_A, bytes, &d));
+    HIPCHK(hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, c->stream));
+    SHCHK(sh_dev_twiddle_scale(c, (uint64_t*)d, rows, log_cols, row0, col0, log_n, inverse));
+    HIPCHK(hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SH_OK;
+}
 int32_t sh_ntt(sh_ctx* c, uint64_t* data, uint32_t log_n, int32_t inverse) {
     CTXCHK(c);
     if (!data) return sh_fail(SH_EINVAL, "sh_ntt: null pointer");
@@ -702,7 +749,29 @@ int32_t sh_dev_fri_fold(sh_ctx* c, const uint64_t* d_cw, size_t L, const uint64_
     if (!fp_is_canonical(a) || !fp_is_canonical(off) || !fp_is_canonical(w)) return sh_fail(SH_EINVAL, "sh_fri_fold: non-canonical scalar");
     if (fp_is_zero(off) || fp_is_zero(w)) return sh_fail(SH_EDIVZERO, "Cannot divide by zero");      // alpha/(offset·omega^i), field.rs:102
     const fp c0 = fp_mul(fp_mul(a, fp_inv(fp_make(2, 0, 0, 0))), fp_inv(off));
-    HIPCHK(launch_fri_fold((const fp*)d_cw, L, fp_to_mont(c0), fp_inv(w), (fp*)d_out, c->stream));
+    HIPCHK(launch_fri_fold((const fp*)d_cw, (const fp*)d_cw + L / 2, L / 2, fp_to_mont(c0), fp_inv(w), (fp*)d_out, c->stream));
+    return SH_OK;
+}
+int32_t sh_dev_fri_fold_range(sh_ctx* c, const uint64_t* d_lo, const uint64_t* d_hi, size_t count, uint64_t i0, const uint64_t alpha[2],
+                              const uint64_t offset[2], const uint64_t omega[2], uint64_t* d_out) {
+    CTXCHK(c);
+    if (!count) return SH_OK;
+    if (!d_lo || !d_hi || !alpha || !offset || !omega || !d_out) return sh_fail(SH_EINVAL, "sh_dev_fri_fold_range: null pointer");
+    const fp a = fp_load_host(alpha), off = fp_load_host(offset), w = fp_load_host(omega);
+    if (!fp_is_canonical(a) || !fp_is_canonical(off) || !fp_is_canonical(w)) return sh_fail(SH_EINVAL, "sh_fri_fold_range: non-canonical scalar");
+    if (fp_is_zero(off) || fp_is_zero(w)) return sh_fail(SH_EDIVZERO, "Cannot divide by zero");      // field.rs:102
+    const fp winv = fp_inv(w);
+    const fp c0 = fp_mul(fp_mul(fp_mul(a, fp_inv(fp_make(2, 0, 0, 0))), fp_inv(off)), fp_pow(winv, i0));
+    HIPCHK(launch_fri_fold((const fp*)d_lo, (const fp*)d_hi, count, fp_to_mont(c0), winv, (fp*)d_out, c->stream));
+    return SH_OK;
+}
+int32_t sh_dev_scale_powers(sh_ctx* c, uint64_t* d_data, size_t count, uint64_t j0, const uint64_t base[2]) {
+    CTXCHK(c);
+    if (!count) return SH_OK;
+    if (!d_data || !base) return sh_fail(SH_EINVAL, "sh_dev_scale_powers: null pointer");
+    const fp b = fp_load_host(base);
+    if (!fp_is_canonical(b)) return sh_fail(SH_EINVAL, "sh_dev_scale_powers: non-canonical base");
+    HIPCHK(launch_scale_powers((fp*)d_data, count, fp_to_mont(fp_pow(b, j0)), b, c->stream));
     return SH_OK;
 }
 int32_t sh_fri_fold(sh_ctx* c, const uint64_t* cw, size_t L, const uint64_t alpha[2], const uint64_t offset[2],

@@ -126,7 +126,8 @@ __device__ __forceinline__ fp fold_one(fp x, fp y, fp t_mont) {     // t_mont = 
 }
 
 #define FOLD_PER_THREAD 4
-__global__ __launch_bounds__(256) void k_fri_fold(const fp* __restrict__ cw, size_t half, fp c0_mont, fp omega_inv,
+// `lo`/`hi` are the two halves (separate pointers: a rank of the distributed commit holds a slice of each).
+__global__ __launch_bounds__(256) void k_fri_fold(const fp* __restrict__ lo, const fp* __restrict__ hi, size_t half, fp c0_mont, fp omega_inv,
                                                   fp* __restrict__ out) {
     const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * FOLD_PER_THREAD;
     if (i0 >= half) return;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void k_fri_fold(const fp* __restrict__ cw, siz
     }
 #pragma unroll 1
     for (int q = 0; q < FOLD_PER_THREAD && i0 + q < half; ++q) {
-        out[i0 + q] = fold_one(cw[i0 + q], cw[half + i0 + q], t);
+        out[i0 + q] = fold_one(lo[i0 + q], hi[i0 + q], t);
         t = mont_mul(t, step);
     }
 }
@@ -201,11 +202,10 @@ hipError_t launch_merkle_tail(const digest64* in, digest64* root, size_t n_in, h
     hipLaunchKernelGGL(k_merkle_tail, dim3(1), dim3(256), 0, s, in, root, (uint32_t)n_in);
     return hipGetLastError();
 }
-hipError_t launch_fri_fold(const fp* cw, size_t L, fp c0_mont, fp omega_inv, fp* out, hipStream_t s) {
-    const size_t half = L / 2;
+hipError_t launch_fri_fold(const fp* lo, const fp* hi, size_t half, fp c0_mont, fp omega_inv, fp* out, hipStream_t s) {
     if (!half) return hipErrorInvalidValue;
     const size_t threads = (half + FOLD_PER_THREAD - 1) / FOLD_PER_THREAD;
-    hipLaunchKernelGGL(k_fri_fold, dim3(grid_for(threads, 256)), dim3(256), 0, s, cw, half, c0_mont, omega_inv, out);
+    hipLaunchKernelGGL(k_fri_fold, dim3(grid_for(threads, 256)), dim3(256), 0, s, lo, hi, half, c0_mont, omega_inv, out);
     return hipGetLastError();
 }
 hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* c0_arr, fp c0_single, const fp* tw_inv, uint32_t log_n_table,

@@ -23,7 +23,10 @@ void ntt_make_plan(uint32_t log_n, NttPlan* plan);
 // tw = [lo (min(n,4096)) | hi (max(n >> 12, 1))] Montgomery-form powers of the (inverse) n-th root.
 // scale_mont: Montgomery-form factor applied at the final store (R mod p == 1, or n^-1·R for the inverse).
 // `data` is transformed in place; `scratch` holds n elements.
-hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, hipStream_t s);
+// `batch` contiguous transforms of 2^plan.log_n elements each; `scratch` holds as many elements as `data`.
+hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s);
+hipError_t launch_scale_powers(fp* data, size_t count, fp start_mont, fp base, hipStream_t s);
+hipError_t launch_twiddle_scale(fp* data, size_t rows, uint32_t log_cols, uint64_t row0, uint64_t col0, const fp* tw, uint32_t log_n, hipStream_t s);
 // out[j] = j < n ? coeffs[j]·offset^j : 0   for j < N  (coset pre-scale + zero pad, G7)
 hipError_t launch_coset_scale_pad(const fp* coeffs, size_t n, fp offset, fp* out, size_t N, hipStream_t s);
 
@@ -46,7 +49,7 @@ hipError_t launch_quad_reduce(const digest64* in, digest64* out, size_t n_in, ui
 
 // ---- hash_kernels.hip (FRI round) ----
 // generic split-and-fold (any omega): out[i] = (a+b)/2 + c0·omega^-i·(a-b),  c0 = alpha/(2·offset)
-hipError_t launch_fri_fold(const fp* cw, size_t L, fp c0_mont, fp omega_inv, fp* out, hipStream_t s);
+hipError_t launch_fri_fold(const fp* lo, const fp* hi, size_t half, fp c0_mont, fp omega_inv, fp* out, hipStream_t s);
 // fused round for B codewords of length L stored back to back: fold each into length L/2 (also back to back in
 // `out`) with twiddles w_N^-(i << tw_shift) from the inverse table of the top-level domain, and emit the 2^K-leaf
 // subtree digests of the folded codewords.  c0 = alpha/(2*offset) in Montgomery form: per codeword from the device

@@ -25,6 +25,7 @@ struct NttPassParams {
     uint32_t is_final, log_r0;    // final pass: bits of digit 0
     uint32_t num_mid, mid_bits[NTT_MAX_PASSES];   // final pass: middle digit widths, most significant first
     uint32_t apply_scale;
+    uint32_t log_tiles;           // tiles per transform (log2); blockIdx.x >> log_tiles = index in the batch
     fp scale;                     // Montgomery form
 };
 
@@ -42,7 +43,10 @@ __global__ __launch_bounds__(256) void k_ntt_pass(NttPassParams p) {
     const uint32_t rs = (p.is_final && p.log_c) ? C + 1 : C;      // padded row stride: transposed fill stays conflict-free
     fp* twr = x + (size_t)R * rs;                                 // w_R^e, e < R/2 (Montgomery form)
     const uint32_t tid = threadIdx.x;
-    const size_t tile = blockIdx.x;
+    const size_t tile = blockIdx.x & ((1u << p.log_tiles) - 1);
+    const size_t xform = (size_t)(blockIdx.x >> p.log_tiles) << p.log_n;   // batched: transforms are contiguous
+    const fp* __restrict__ in = p.in + xform;
+    fp* __restrict__ out = p.out + xform;
 
     for (uint32_t e = tid; e < (R >> 1); e += blockDim.x) twr[e] = ntt_load_tw(p.tw, p.log_n, (size_t)e << (p.log_n - p.log_r));
 
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass(NttPassParams p) {
         row_stride_in = (size_t)1 << log_mp;
         for (uint32_t idx = tid; idx < T; idx += blockDim.x) {
             const uint32_t r = idx >> p.log_c, c = idx & (C - 1);
-            x[r * rs + c] = p.in[base + (size_t)r * row_stride_in + c];
+            x[r * rs + c] = in[base + (size_t)r * row_stride_in + c];
         }
     } else {
         const size_t chunks = (size_t)1 << (p.log_r0 - p.log_c);  // chunks of digit-0 values
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass(NttPassParams p) {
         row_stride_in = (size_t)1 << (p.log_n - p.log_r0);        // stride of digit 0 in the in-place layout
         for (uint32_t idx = tid; idx < T; idx += blockDim.x) {
             const uint32_t c = idx >> p.log_r, r = idx & (R - 1); // contiguous digit fastest: coalesced rows
-            x[r * rs + c] = p.in[(size_t)(colbase + c) * row_stride_in + base + r];
+            x[r * rs + c] = in[(size_t)(colbase + c) * row_stride_in + base + r];
         }
     }
     __syncthreads();
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass(NttPassParams p) {
             fp v = x[r * rs + c];
             const size_t e = ((size_t)(colbase + c) * k) << tw_shift;
             v = mont_mul(v, ntt_load_tw(p.tw, p.log_n, e));
-            p.out[base + (size_t)k * row_stride_in + c] = v;
+            out[base + (size_t)k * row_stride_in + c] = v;
         }
     } else {
         // out index = k_0 + R_0·(midrev + M·k_last)
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass(NttPassParams p) {
             const uint32_t k = p.log_r ? (__brev(r) >> (32 - p.log_r)) : 0;
             fp v = x[r * rs + c];
             if (p.apply_scale) v = mont_mul(v, p.scale);
-            p.out[(size_t)(colbase + c) + ((((size_t)k << log_M) + midrev) << p.log_r0)] = v;
+            out[(size_t)(colbase + c) + ((((size_t)k << log_M) + midrev) << p.log_r0)] = v;
         }
     }
 }
@@ -143,7 +147,7 @@ static size_t pass_lds_bytes(uint32_t log_r, uint32_t log_c, bool is_final) {
     return (R * rs + (R >> 1) + 1) * sizeof(fp);
 }
 
-hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, hipStream_t s) {
+hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -176,7 +180,9 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
             p.in = (P >= 2) ? scratch : data;
             p.out = data;
         }
-        const size_t tiles = ((size_t)1 << log_n) >> (p.log_r + p.log_c);
+        p.log_tiles = log_n - (p.log_r + p.log_c);
+        const size_t tiles = ((size_t)1 << p.log_tiles) * batch;
+        if (tiles > 0x7fffffffu) return hipErrorInvalidValue;
         const size_t lds = pass_lds_bytes(p.log_r, p.log_c, is_final);
         hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(256), lds, s, p);
         hipError_t e = hipGetLastError();
@@ -212,5 +218,48 @@ __global__ __launch_bounds__(256) void k_coset_scale_pad(const fp* __restrict__ 
 hipError_t launch_coset_scale_pad(const fp* coeffs, size_t n, fp offset, fp* out, size_t N, hipStream_t s) {
     const size_t threads = (N + SCALE_PER_THREAD - 1) / SCALE_PER_THREAD;
     hipLaunchKernelGGL(k_coset_scale_pad, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, coeffs, n, offset, out, N);
+    return hipGetLastError();
+}
+
+// data[r][c] *= w_n^((row0 + r)·(col0 + c)) for a rows × 2^log_cols row-major block: the twiddle between the
+// two transform steps of a four-step NTT whose steps run as separate batched transforms (dist_ntt.py).
+__global__ __launch_bounds__(256) void k_twiddle_scale(fp* __restrict__ data, size_t total, uint32_t log_cols, uint64_t row0, uint64_t col0,
+                                                       const fp* __restrict__ tw, uint32_t log_n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t r = row0 + (i >> log_cols), c = col0 + (i & (((size_t)1 << log_cols) - 1));
+    const uint64_t nmask = ((uint64_t)1 << log_n) - 1;
+    const uint64_t e = ((r & nmask) * (c & nmask)) & nmask;      // r, c < 2^32: the product fits 64 bits
+    data[i] = mont_mul(data[i], ntt_load_tw(tw, log_n, e));
+}
+
+hipError_t launch_twiddle_scale(fp* data, size_t rows, uint32_t log_cols, uint64_t row0, uint64_t col0, const fp* tw, uint32_t log_n, hipStream_t s) {
+    const size_t total = rows << log_cols;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(k_twiddle_scale, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, data, total, log_cols, row0, col0, tw, log_n);
+    return hipGetLastError();
+}
+
+// data[i] *= start·base^i (start in Montgomery form = base^j0): the coset pre-scale of a slice [j0, j0+count) of a
+// coefficient vector that is spread over ranks.
+__global__ __launch_bounds__(256) void k_scale_powers(fp* __restrict__ data, size_t count, fp start_mont, fp base) {
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * SCALE_PER_THREAD;
+    if (i0 >= count) return;
+    fp step = fp_to_mont(base), b = step, t = start_mont;
+    for (size_t e = i0; e; e >>= 1) {
+        if (e & 1) t = mont_mul(t, b);
+        b = mont_mul(b, b);
+    }
+#pragma unroll 1
+    for (int q = 0; q < SCALE_PER_THREAD && i0 + q < count; ++q) {
+        data[i0 + q] = mont_mul(data[i0 + q], t);
+        t = mont_mul(t, step);
+    }
+}
+
+hipError_t launch_scale_powers(fp* data, size_t count, fp start_mont, fp base, hipStream_t s) {
+    const size_t threads = (count + SCALE_PER_THREAD - 1) / SCALE_PER_THREAD;
+    if (!threads) return hipSuccess;
+    hipLaunchKernelGGL(k_scale_powers, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, data, count, start_mont, base);
     return hipGetLastError();
 }

@@ -1,0 +1,363 @@
+"""
+dist_ntt.py — ONE transform / ONE commit spread over several GPUs (BASELINE.json C5): the
+four-step NTT with all-to-all transposes and the FRI commit of a codeword that is sharded over ranks.
+One process per GPU under torch.distributed ("nccl" == RCCL over xGMI; "gloo" for CPU rehearsals and for
+several ranks on one card, where tensors are staged through host memory).
+
+Data model.  A vector of n = 2^log_n field elements is spread in natural order: rank r of P holds the contiguous
+slice [r·n/P, (r+1)·n/P) as an int64 tensor of shape (n/P, 2) ({lo, hi} words of the canonical value, the bytes the
+C ABI uses; torch has no uint64 arithmetic and none is needed — torch only moves and permutes).
+
+Four-step NTT (n = n1·n2, j = j1·n2 + j2, k = k1 + n1·k2):
+  A  exchange-transpose  rows j1 -> columns j2      [all-to-all]      (skipped for input_layout="columns")
+  B  n2/P local NTTs of n1 points over j1, then  ·w_n^(j2·k1)         [sh_dev_ntt_batch, sh_dev_twiddle_scale]
+  C  exchange-transpose  columns j2 -> rows k1      [all-to-all]
+  D  n1/P local NTTs of n2 points over j2                             [sh_dev_ntt_batch]
+  E  exchange-transpose  rows k1 -> natural order   [all-to-all]      (skipped for output_layout="rows")
+Every all-to-all moves the rank's whole slice once (16·n/P bytes out, 16·n/P in); xGMI is point-to-point, so an
+all-to-all is the collective it is best at (every link busy, one hop).
+
+Sharded FRI commit.  Round r works on a codeword of length L.  Rank g holds half-slices g and P+g (h = L/(2P)
+elements each), so cw[i] and cw[L/2+i] are on the same card: it hashes both into Merkle sub-roots (GPU), the 2P
+sub-roots are all-gathered (128 B per rank) and reduced to the round's root on every rank, every rank keeps an
+identical transcript replica and derives the same alpha, and the fold of the rank's h outputs is local.  The h
+outputs are slice g of the next codeword; before the next round a point-to-point regroup moves its two halves to
+ranks 2g mod P and (2g+1) mod P.  When slices get small the codeword is all-gathered and every rank finishes the
+remaining rounds locally (the round count depends on the current length only).
+
+`engine` is the local compute.  `GpuEngine` is the product engine (HIP kernels through the C ABI, no fallback);
+tests inject a CPU engine with the same methods to rehearse the exchange logic on gloo ranks.
+"""
+import contextlib
+import ctypes as C
+import os
+
+import numpy as np
+
+_MASK = 0xFFFFFFFFFFFFFFFF
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def _world_rank(group):
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _needs_staging(t, group):
+    return t.is_cuda and _dist().get_backend(group) != "nccl"
+
+
+# ------------------------------------------------------------------------------------------------ GPU engine
+class GpuEngine:
+    """local steps on this rank's MI355X.  All kernels and all torch work run on one non-default HIP stream."""
+
+    def __init__(self, device=None):
+        import torch
+        from ._lib import lib  # noqa: F401  (ImportError if the HIP library is not built: there is no CPU path)
+        from .context import Context
+        dev = int(os.environ.get("LOCAL_RANK", "0")) if device is None else int(device)
+        if not torch.cuda.is_available():
+            raise RuntimeError("GpuEngine needs a HIP device; stark_anatomy_amd has no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", dev)
+        self.stream = torch.cuda.Stream(self.device)
+        self.ctx = Context(dev, stream=self.stream.cuda_stream)
+
+    def scope(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def from_host(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, 2)
+        with self.scope():
+            return self.torch.from_numpy(a.view(np.int64)).to(self.device)
+
+    def to_host(self, t):
+        with self.scope():
+            h = t.contiguous().cpu()
+        return h.numpy().view(np.uint64).reshape(-1, 2)
+
+    def _chk(self, rc):
+        from ._lib import check
+        check(rc)
+
+    @staticmethod
+    def _sc(v):
+        from .context import _u64p, scalar
+        s = scalar(int(v))
+        return s, _u64p(s)
+
+    def ntt_rows(self, t, log_len, inverse=False):
+        """in place: every contiguous run of 2^log_len elements of `t` is transformed."""
+        from ._lib import lib
+        assert t.is_contiguous() and (t.numel() // 2) % (1 << log_len) == 0
+        self._chk(lib.sh_dev_ntt_batch(self.ctx.handle, t.data_ptr(), (t.numel() // 2) >> log_len, log_len, int(bool(inverse))))
+        return t
+
+    def twiddle(self, t, log_cols, row0, col0, log_n, inverse=False):
+        from ._lib import lib
+        assert t.is_contiguous()
+        self._chk(lib.sh_dev_twiddle_scale(self.ctx.handle, t.data_ptr(), (t.numel() // 2) >> log_cols, log_cols, row0, col0, log_n, int(bool(inverse))))
+        return t
+
+    def scale_powers(self, t, j0, base):
+        from ._lib import lib
+        assert t.is_contiguous()
+        keep, p = self._sc(base)
+        self._chk(lib.sh_dev_scale_powers(self.ctx.handle, t.data_ptr(), t.numel() // 2, j0, p))
+        return t
+
+    def subroot(self, t):
+        """Merkle root over the leaf hashes of the elements of `t` (a power-of-two count)."""
+        from ._lib import lib
+        from .context import _u8p
+        assert t.is_contiguous()
+        root = np.zeros(64, dtype=np.uint8)
+        self._chk(lib.sh_dev_merkle_commit_elems(self.ctx.handle, t.data_ptr(), t.numel() // 2, _u8p(root)))
+        return root.tobytes()
+
+    def top_root(self, digests):
+        from ._lib import lib
+        from .context import _u8p
+        arr = np.frombuffer(b"".join(digests), dtype=np.uint8).copy()
+        root = np.zeros(64, dtype=np.uint8)
+        self._chk(lib.sh_merkle_commit(self.ctx.handle, _u8p(arr), len(digests), _u8p(root)))
+        return root.tobytes()
+
+    def fold_range(self, lo, hi, i0, alpha, offset, omega):
+        from . import _lib
+        assert lo.is_contiguous() and hi.is_contiguous() and lo.shape == hi.shape
+        with self.scope():
+            out = self.torch.empty_like(lo)
+        k1, a = self._sc(alpha)
+        k2, o = self._sc(offset)
+        k3, w = self._sc(omega)
+        rc = _lib.lib.sh_dev_fri_fold_range(self.ctx.handle, lo.data_ptr(), hi.data_ptr(), lo.numel() // 2, i0, a, o, w, out.data_ptr())
+        if rc == _lib.SH_EDIVZERO:
+            raise ZeroDivisionError("Cannot divide by zero")
+        self._chk(rc)
+        return out
+
+    def commit_tail(self, cw, L, offset, expansion, t, proof_stream):
+        """the remaining rounds of a commit whose current codeword (L elements, whole) is on this rank."""
+        from .fri import Fri
+        roots, last = Fri(offset, None, L, expansion, t, ctx=self.ctx).commit(cw.contiguous(), proof_stream)
+        return [h.as_bytes() for h in roots], last
+
+    def new_proof_stream(self):
+        from .proof_stream import ProofStream
+        return ProofStream()
+
+    def root_of_unity(self, log_n):
+        from .field import root_of_unity
+        return root_of_unity(log_n).value()
+
+    def push_root_and_sample(self, ps, root):
+        """push(MerkleRoot) then alpha = sample(prover_fiat_shamir())"""
+        from .fri import sample
+        from .proof_stream import ProofItem
+        ps.push(ProofItem.MerkleRoot(root))
+        return sample(ps.prover_fiat_shamir()).value()
+
+
+# ------------------------------------------------------------------------------------------------ exchanges
+def _all_to_all(send, group):
+    """send: (P, ...) contiguous; block s goes to rank s; returns (P, ...) with block s received from rank s."""
+    import torch
+    dist = _dist()
+    if _needs_staging(send, group):
+        s = send.cpu()
+        r = torch.empty_like(s)
+        dist.all_to_all_single(r, s, group=group)
+        return r.to(send.device)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    return recv
+
+
+def exchange_transpose(x, group=None):
+    """The global matrix is (P·a) × (P·b) elements, row-major, rank r holding rows [r·a, (r+1)·a) as x of shape
+    (a, P·b, 2).  Returns this rank's columns [r·b, (r+1)·b) as rows: shape (b, P·a, 2)."""
+    P, _ = _world_rank(group)
+    a, cols = x.shape[0], x.shape[1]
+    assert cols % P == 0, "column count must be divisible by the number of ranks"
+    b = cols // P
+    if P == 1:
+        return x.transpose(0, 1).contiguous()
+    send = x.view(a, P, b, 2).permute(1, 2, 0, 3).contiguous()       # [dest s][col c][row]
+    recv = _all_to_all(send, group)                                   # [src s][col c][row of s]
+    return recv.permute(1, 0, 2, 3).reshape(b, P * a, 2).contiguous()
+
+
+def _all_gather_bytes(b, group, device):
+    import torch
+    dist = _dist()
+    P, _ = _world_rank(group)
+    if P == 1:
+        return [b]
+    stage = device.type == "cuda" and dist.get_backend(group) != "nccl"
+    dev = torch.device("cpu") if stage else device
+    t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    out = torch.empty(P * len(b), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, t, group=group)
+    raw = out.cpu().numpy().tobytes()
+    return [raw[i * len(b):(i + 1) * len(b)] for i in range(P)]
+
+
+def all_gather_slices(x, group=None):
+    """concatenate the ranks' (m, 2) slices in rank order -> (P·m, 2) on every rank."""
+    import torch
+    dist = _dist()
+    P, _ = _world_rank(group)
+    if P == 1:
+        return x
+    src = x.contiguous()
+    if _needs_staging(src, group):
+        s = src.cpu()
+        out = torch.empty((P * s.shape[0], 2), dtype=s.dtype)
+        dist.all_gather_into_tensor(out, s, group=group)
+        return out.to(x.device)
+    out = torch.empty((P * src.shape[0], 2), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group)
+    return out
+
+
+def _regroup(chunk, group):
+    """chunk = slice g of P of the codeword (halves 2g, 2g+1 of 2P).  Returns (half g, half P+g)."""
+    import torch
+    dist = _dist()
+    P, g = _world_rank(group)
+    h = chunk.shape[0] // 2
+    parts = (chunk[:h].contiguous(), chunk[h:].contiguous())
+    if P == 1:
+        return parts
+    stage = _needs_staging(chunk, group)
+    got = {}
+    ops, keep = [], []
+    for q in (0, 1):                                  # half 2g+q goes to rank (2g+q) mod P, as lo when 2g+q < P
+        idx = 2 * g + q
+        dst = idx % P
+        if dst == g:
+            got[idx] = parts[q]
+        else:
+            buf = parts[q].cpu() if stage else parts[q]
+            keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, dst if group is None else dist.get_global_rank(group, dst), group=group))
+    for idx in (g, P + g):                            # half idx lives on rank idx // 2
+        src = idx // 2
+        if src != g:
+            buf = torch.empty((h, 2), dtype=chunk.dtype, device="cpu" if stage else chunk.device)
+            got[idx] = buf
+            ops.append(dist.P2POp(dist.irecv, buf, src if group is None else dist.get_global_rank(group, src), group=group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    lo, hi = got[g], got[P + g]
+    if stage:
+        lo, hi = lo.to(chunk.device), hi.to(chunk.device)
+    return lo, hi
+
+
+# ------------------------------------------------------------------------------------------------ four-step NTT
+def split_log(log_n):
+    """(log n1, log n2): rows x columns of the four-step matrix, n1 <= n2."""
+    return log_n // 2, log_n - log_n // 2
+
+
+def dist_ntt(local, log_n, engine, group=None, inverse=False, input_layout="natural", output_layout="natural"):
+    """NTT of the 2^log_n-point vector whose slice this rank holds (see module docstring for the layouts).
+    input_layout  "natural": local = x[g·n/P : (g+1)·n/P];  "columns": local[c][j1] = x[j1·n2 + g·n2/P + c].
+    output_layout "natural": returns X[g·n/P : (g+1)·n/P];  "rows":    returns [k1l][k2] = X[g·n1/P + k1l + n1·k2]."""
+    P, g = _world_rank(group)
+    l1, l2 = split_log(log_n)
+    n1, n2 = 1 << l1, 1 << l2
+    if n1 % P or n2 % P:
+        raise ValueError(f"2^{l1} x 2^{l2} matrix does not split over {P} ranks")
+    if local.numel() != 2 * (n1 * n2 // P):
+        raise ValueError("local slice has the wrong length")
+    with engine.scope():
+        if input_layout == "natural":
+            y = exchange_transpose(local.reshape(n1 // P, n2, 2), group)        # (n2/P, n1, 2): [j2l][j1]
+        elif input_layout == "columns":
+            y = local.reshape(n2 // P, n1, 2).contiguous()
+        else:
+            raise ValueError(input_layout)
+        engine.ntt_rows(y, l1, inverse)                                          # [j2l][k1]
+        engine.twiddle(y, l1, g * (n2 // P), 0, log_n, inverse)
+        z = exchange_transpose(y, group)                                         # (n1/P, n2, 2): [k1l][j2]
+        engine.ntt_rows(z, l2, inverse)                                          # [k1l][k2] = X[k1 + n1·k2]
+        if output_layout == "rows":
+            return z
+        if output_layout != "natural":
+            raise ValueError(output_layout)
+        return exchange_transpose(z, group).reshape(-1, 2)                       # [k2l][k1] = natural slice
+
+
+def dist_coset_lde(local_coeffs, log_n, log_expansion, offset, engine, group=None):
+    """coset LDE of a polynomial with 2^log_n coefficients spread in natural order: returns this
+    rank's natural-order slice of the 2^(log_n+log_expansion) evaluations f(offset·w^i).  Each rank scales its
+    coefficients by offset^j, the zero padding is laid out by slice arithmetic (no traffic), then dist_ntt."""
+    import torch
+    P, g = _world_rank(group)
+    n, N = 1 << log_n, 1 << (log_n + log_expansion)
+    m_in, m_out = n // P, N // P
+    if local_coeffs.numel() != 2 * m_in:
+        raise ValueError("local coefficient slice has the wrong length")
+    with engine.scope():
+        scaled = engine.scale_powers(local_coeffs.reshape(-1, 2).clone(), g * m_in, offset)
+        # padded vector = [coeffs | zeros]; rank g owns padded[g·m_out, (g+1)·m_out): gather the coefficient slices
+        # that fall in it (they come from ranks g·2^e … only when g < P/2^e; others own zeros).
+        full = all_gather_slices(scaled, group) if P > 1 else scaled
+        mine = torch.zeros((m_out, 2), dtype=scaled.dtype, device=scaled.device)
+        lo, hi = g * m_out, min((g + 1) * m_out, n)
+        if lo < n:
+            mine[: hi - lo] = full[lo:hi]
+    return dist_ntt(mine, log_n + log_expansion, engine, group)
+
+
+# ------------------------------------------------------------------------------------------------ sharded FRI commit
+def _num_rounds(L, expansion, t):
+    r = 0
+    while L > expansion and 4 * t < L:
+        L //= 2
+        r += 1
+    return r
+
+
+def _mul_mod(a, b):
+    from .field import PRIME
+    return (a * b) % PRIME
+
+
+def dist_fri_commit(local, N, engine, offset, expansion_factor=4, num_colinearity_tests=17, group=None,
+                    proof_stream=None, min_half=1 << 10):
+    """FRI commit of ONE codeword of N elements spread in natural order over the ranks.
+    Every rank returns (roots [R × 64 B], last_codeword (L,2) uint64, proof_stream) — identical on all ranks."""
+    P, g = _world_rank(group)
+    if N % P or (N // P) < 2:
+        raise ValueError("codeword does not split over the ranks")
+    if local.numel() != 2 * (N // P):
+        raise ValueError("local slice has the wrong length")
+    ps = proof_stream if proof_stream is not None else engine.new_proof_stream()
+    offset = int(offset.value() if hasattr(offset, "value") else offset)
+    L, chunk, roots = N, local.reshape(-1, 2), []
+    with engine.scope():
+        while L // (2 * P) >= max(1, min_half) and _num_rounds(L, expansion_factor, num_colinearity_tests) > 1:
+            lo, hi = _regroup(chunk, group)
+            pair = engine.subroot(lo) + engine.subroot(hi)
+            subs = _all_gather_bytes(pair, group, chunk.device)
+            root = engine.top_root([s[:64] for s in subs] + [s[64:] for s in subs])
+            roots.append(root)
+            alpha = engine.push_root_and_sample(ps, root)
+            log_L = L.bit_length() - 1
+            chunk = engine.fold_range(lo, hi, g * (L // (2 * P)), alpha, offset, engine.root_of_unity(log_L))
+            offset = _mul_mod(offset, offset)
+            L //= 2
+        full = all_gather_slices(chunk, group)
+        tail_roots, last = engine.commit_tail(full, L, offset, expansion_factor, num_colinearity_tests, ps)
+    return roots + list(tail_roots), last, ps

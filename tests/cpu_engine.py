@@ -1,0 +1,81 @@
+"""
+cpu_engine.py — TEST INFRASTRUCTURE: a local engine for stark_anatomy_amd.dist_ntt built on the CPU oracle, with the
+same methods as dist_ntt.GpuEngine, so that the exchange logic (all-to-all transposes, regroup, sub-root gather) can
+be rehearsed on gloo ranks without a GPU.  The product never imports this file (tests/test_abi_and_host.py checks).
+"""
+import contextlib
+
+import numpy as np
+import torch
+
+from oracle import coracle as co
+from oracle import pyoracle as po
+
+
+def _np(t):
+    return t.contiguous().numpy().view(np.uint64).reshape(-1, 2)
+
+
+def _put(t, arr):
+    t.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).view(np.int64)).reshape(t.shape))
+    return t
+
+
+class OracleEngine:
+    device = torch.device("cpu")
+
+    def scope(self):
+        return contextlib.nullcontext()
+
+    def from_host(self, arr):
+        return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, 2).view(np.int64).copy())
+
+    def to_host(self, t):
+        return _np(t).copy()
+
+    def ntt_rows(self, t, log_len, inverse=False):
+        a = _np(t).reshape(-1, 1 << log_len, 2)
+        return _put(t, np.stack([co.ntt(row, inverse) for row in a]))
+
+    def twiddle(self, t, log_cols, row0, col0, log_n, inverse=False):
+        w = po.root_of_unity(log_n)
+        if inverse:
+            w = po.fp_inv(w)
+        n = 1 << log_n
+        vals = co.to_ints(_np(t))
+        cols = 1 << log_cols
+        out = [po.fp_mul(v, pow(w, ((row0 + i // cols) * (col0 + i % cols)) % n, po.P)) for i, v in enumerate(vals)]
+        return _put(t, co.to_arr(out))
+
+    def scale_powers(self, t, j0, base):
+        vals = co.to_ints(_np(t))
+        return _put(t, co.to_arr([po.fp_mul(v, pow(int(base), j0 + i, po.P)) for i, v in enumerate(vals)]))
+
+    def subroot(self, t):
+        return co.merkle_commit_elems(_np(t))
+
+    def top_root(self, digests):
+        return po.merkle_commit(list(digests))
+
+    def fold_range(self, lo, hi, i0, alpha, offset, omega):
+        x, y = co.to_ints(_np(lo)), co.to_ints(_np(hi))
+        inv2 = po.fp_inv(2)
+        out = []
+        for k, (a, b) in enumerate(zip(x, y)):        # G4, literally, at global index i0+k
+            q = po.fp_div(alpha, po.fp_mul(offset, pow(omega, i0 + k, po.P)))
+            out.append(po.fp_mul(inv2, po.fp_add(po.fp_mul(po.fp_add(1, q), a), po.fp_mul(po.fp_sub(1, q), b))))
+        return self.from_host(co.to_arr(out))
+
+    def commit_tail(self, cw, L, offset, expansion, t, proof_stream):
+        roots, _, last, _ = co.fri_commit(_np(cw), expansion, t, offset, ps=proof_stream)
+        return roots, last
+
+    def new_proof_stream(self):
+        return co.ProofStream()
+
+    def root_of_unity(self, log_n):
+        return po.root_of_unity(log_n)
+
+    def push_root_and_sample(self, ps, root):
+        ps.push_root(root)
+        return co.sample(ps.prover_fiat_shamir())

@@ -1,0 +1,175 @@
+"""
+GPU parity tests for the local steps of the multi-GPU path (batched NTT, four-step twiddle, ranged coset scale,
+ranged fold) and for dist_ntt.GpuEngine: in one process (P = 1: the four-step decomposition itself), and with two
+ranks sharing cuda:0 over gloo (tensors staged through host memory) so that the all-to-all transposes, the regroup
+and the sub-root gather run with the real kernels.  Bit-exact against the CPU oracle.
+"""
+import ctypes as C
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402,F401  (before stark_anatomy_amd)
+
+import stark_anatomy_amd as sa  # noqa: E402
+from oracle import coracle as co  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+from stark_anatomy_amd import _lib  # noqa: E402
+from stark_anatomy_amd.context import _u64p, scalar  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P, G = po.P, po.G
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sa.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("batch,log_len", [(1, 5), (7, 0), (3, 1), (5, 8), (64, 9), (16, 12), (3, 13), (4, 17)])
+def test_ntt_batch_vs_oracle(ctx, batch, log_len):
+    n = 1 << log_len
+    x = co.splitmix_elems(500 + batch + log_len, batch * n)
+    for inverse in (False, True):
+        a = x.copy()
+        _lib.check(_lib.lib.sh_ntt_batch(ctx.handle, _u64p(a), batch, log_len, int(inverse)))
+        exp = np.concatenate([co.ntt(x[b * n:(b + 1) * n], inverse) for b in range(batch)])
+        assert np.array_equal(a, exp)
+
+
+def test_ntt_batch_rejects_oversize(ctx):
+    a = np.zeros((2, 2), dtype=np.uint64)
+    assert _lib.lib.sh_ntt_batch(ctx.handle, _u64p(a), 1, 29, 0) == _lib.SH_EINVAL
+    assert _lib.lib.sh_ntt_batch(ctx.handle, _u64p(a), 1 << 40, 10, 0) == _lib.SH_EINVAL
+    assert _lib.lib.sh_ntt_batch(ctx.handle, None, 0, 10, 0) == _lib.SH_OK
+
+
+@pytest.mark.parametrize("rows,log_cols,row0,col0,log_n", [(5, 3, 0, 0, 6), (8, 4, 24, 0, 9), (3, 2, 1000, 7, 14), (16, 6, 4080, 0, 20)])
+def test_twiddle_scale_vs_python(ctx, rows, log_cols, row0, col0, log_n):
+    cols = 1 << log_cols
+    x = co.splitmix_elems(9, rows * cols)
+    vals = co.to_ints(x)
+    for inverse in (False, True):
+        a = x.copy()
+        _lib.check(_lib.lib.sh_twiddle_scale(ctx.handle, _u64p(a), rows, log_cols, row0, col0, log_n, int(inverse)))
+        w = po.root_of_unity(log_n)
+        if inverse:
+            w = po.fp_inv(w)
+        exp = [v * pow(w, ((row0 + i // cols) * (col0 + i % cols)) % (1 << log_n), P) % P for i, v in enumerate(vals)]
+        assert co.to_ints(a) == exp
+
+
+def test_scale_powers_and_fold_range_vs_oracle(ctx):
+    n = 1 << 12
+    x = co.splitmix_elems(21, n)
+    d = ctx.alloc(n * 16).upload(x)
+    j0 = 123456
+    _lib.check(_lib.lib.sh_dev_scale_powers(ctx.handle, d.ptr, n, j0, _u64p(scalar(G))))
+    got = co.to_ints(d.download(np.uint64, (n, 2)))
+    assert got == [v * pow(G, j0 + i, P) % P for i, v in enumerate(co.to_ints(x))]
+    # ranged fold == the matching slice of the oracle's whole-codeword fold
+    L, alpha, off = n, 0x1234567890abcdef1234567890abcdef % P, pow(G, 4, P)
+    omega = po.root_of_unity(12)
+    exp = co.fri_fold(x, alpha, off, omega)
+    d.upload(x)
+    for i0, cnt in [(0, L // 2), (512, 512), (2047, 1), (100, 37)]:
+        out = ctx.alloc(cnt * 16)
+        _lib.check(_lib.lib.sh_dev_fri_fold_range(ctx.handle, d.ptr + 16 * i0, d.ptr + 16 * (L // 2 + i0), cnt, i0, _u64p(scalar(alpha)),
+                                                  _u64p(scalar(off)), _u64p(scalar(omega)), out.ptr))
+        assert np.array_equal(out.download(np.uint64, (cnt, 2)), exp[i0:i0 + cnt])
+    assert _lib.lib.sh_dev_fri_fold_range(ctx.handle, d.ptr, d.ptr, 4, 0, _u64p(scalar(alpha)), _u64p(scalar(0)), _u64p(scalar(omega)), d.ptr) == _lib.SH_EDIVZERO
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from stark_anatomy_amd.dist_ntt import GpuEngine
+    return GpuEngine(0)
+
+
+@pytest.mark.parametrize("log_n", [2, 9, 16, 20])
+def test_four_step_single_rank(engine, log_n):
+    """P = 1: the four-step decomposition (batched column NTTs, twiddle, batched row NTTs, torch transposes) equals the
+    direct transform; at 2^20 against the library's own one-shot NTT, below that against the oracle."""
+    from stark_anatomy_amd import dist_ntt as dn
+    n = 1 << log_n
+    x = co.splitmix_elems(31 + log_n, n)
+    X = engine.to_host(dn.dist_ntt(engine.from_host(x), log_n, engine))
+    exp = co.ntt(x) if log_n <= 16 else sa.ntt(x, ctx=engine.ctx)
+    assert np.array_equal(X, exp)
+    back = engine.to_host(dn.dist_ntt(engine.from_host(X), log_n, engine, inverse=True))
+    assert np.array_equal(back, x)
+
+
+def test_dist_lde_and_commit_single_rank(engine):
+    from stark_anatomy_amd import dist_ntt as dn
+    log_n = 14
+    c = co.splitmix_elems(5, 1 << log_n)
+    cw = dn.dist_coset_lde(engine.from_host(c), log_n, 2, G, engine)
+    exp_cw = co.coset_lde(c, 2, G)
+    assert np.array_equal(engine.to_host(cw), exp_cw)
+    roots, last, ps = dn.dist_fri_commit(cw, 1 << (log_n + 2), engine, G, 4, 17, min_half=1 << 8)
+    r, _, l, ops = co.fri_commit(exp_cw, 4, 17, G)
+    assert [bytes(a) for a in roots] == r and np.array_equal(last, l) and ps.serialize() == ops.serialize()
+
+
+WORKER = r'''
+import os, sys, pickle
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["REPO_ROOT"])
+from stark_anatomy_amd import dist_ntt as dn
+from stark_anatomy_amd.field import GENERATOR
+
+dist.init_process_group("gloo")
+P, g = dist.get_world_size(), dist.get_rank()
+eng = dn.GpuEngine(0)                         # both ranks share cuda:0; gloo stages tensors through the host
+log_n = int(os.environ["TEST_LOG_N"]); n = 1 << log_n
+x = np.load(os.environ["TEST_IN"])
+sl = lambda a, m: a[g * (m // P):(g + 1) * (m // P)]
+res = {}
+X = dn.dist_ntt(eng.from_host(sl(x, n)), log_n, eng)
+res["ntt"] = eng.to_host(X)
+m = n // 4
+cw = dn.dist_coset_lde(eng.from_host(sl(x[:m], m)), log_n - 2, 2, GENERATOR, eng)
+res["lde"] = eng.to_host(cw)
+roots, last, ps = dn.dist_fri_commit(cw, n, eng, GENERATOR, 4, 17, min_half=256)
+res["fri"] = (roots, np.asarray(last), ps.serialize())
+out = [None] * P if g == 0 else None
+dist.gather_object(res, out, dst=0)
+dist.barrier(); dist.destroy_process_group()
+if g == 0:
+    pickle.dump(out, open(os.environ["TEST_OUT"], "wb"))
+'''
+
+
+def test_two_ranks_one_gpu_gloo(tmp_path):
+    log_n = 14
+    n = 1 << log_n
+    x = co.splitmix_elems(99, n)
+    np.save(tmp_path / "in.npy", x)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "out.pkl"
+    env = dict(os.environ, REPO_ROOT=ROOT, TEST_LOG_N=str(log_n), TEST_IN=str(tmp_path / "in.npy"), TEST_OUT=str(out),
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    parts = pickle.load(open(out, "rb"))
+    assert np.array_equal(np.concatenate([p["ntt"] for p in parts]), co.ntt(x))
+    exp_cw = co.coset_lde(x[: n // 4], 2, G)
+    assert np.array_equal(np.concatenate([p["lde"] for p in parts]), exp_cw)
+    r0, _, l0, ps0 = co.fri_commit(exp_cw, 4, 17, G)
+    for p in parts:
+        roots, last, s = p["fri"]
+        assert [bytes(a) for a in roots] == r0 and np.array_equal(last, l0) and s == ps0.serialize()
