@@ -70,11 +70,17 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
             sys.exit(2)
+    backend = os.environ.get("STARK_BENCH_BACKEND", "nccl")       # "gloo" + STARK_BENCH_SHARE_GPU=1: rehearsal of N ranks on one card
+    if os.environ.get("STARK_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if dist is not None:
@@ -222,6 +228,66 @@ def main():
         d_o.free()
     out["extra"] = extra
 
+    # ---- N > 1 only: ONE 2^log_n transform / commit spread over all ranks (BASELINE config 5; strong scaling, RCCL
+    # all-to-all over xGMI).  Reported beside the headline, never as `value`.  Runs under a watchdog: if a collective
+    # stalls, the headline line is still printed and the process leaves.
+    if world > 1 and not args.no_extra and os.environ.get("STARK_BENCH_DIST", "1") != "0":
+        import threading
+        box = {}
+
+        def dist_leg():
+            try:
+                torch.cuda.set_device(local_rank)
+                from stark_anatomy_amd import dist_ntt as dn
+                eng = dn.GpuEngine(local_rank)
+                m = N // world
+                seed = np.frombuffer(np.random.default_rng(4242 + rank).bytes(16 * m), dtype=np.uint64).reshape(m, 2)
+                red = np.empty_like(seed)
+                _lib.check(_lib.lib.sh_fp_new(H, _u64p(np.ascontiguousarray(seed)), _u64p(red), m))
+                x = eng.from_host(red)
+                res = {}
+
+                def t_max(fn, reps):
+                    fn()
+                    dist.barrier(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        r = fn()
+                    torch.cuda.synchronize(); dist.barrier()
+                    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    return float(t.item()) / reps, r
+                t_ntt, X = t_max(lambda: dn.dist_ntt(x, log_n, eng), 3)
+                res[f"ntt_2^{log_n}_ms"] = 1e3 * t_ntt
+                res[f"ntt_2^{log_n}_GBps"] = 32.0 * N / t_ntt / 1e9
+                t_rows, _ = t_max(lambda: dn.dist_ntt(x, log_n, eng, output_layout="rows"), 3)
+                res[f"ntt_2^{log_n}_rows_layout_ms"] = 1e3 * t_rows
+                back = dn.dist_ntt(X, log_n, eng, inverse=True)
+                with eng.scope():
+                    ok = bool(torch.equal(back, x))
+                t_fri, (roots, last, _ps) = t_max(lambda: dn.dist_fri_commit(X, N, eng, sa.GENERATOR, 4, 17), 2)
+                res[f"fri_commit_2^{log_n}_ms"] = 1e3 * t_fri
+                res[f"fri_commit_2^{log_n}_elems_per_s"] = N / t_fri
+                full = dn.all_gather_slices(X)
+                torch.cuda.synchronize()
+                r1, _l1 = sa.Fri(sa.GENERATOR, None, N, 4, 17, ctx=eng.ctx).commit(full, sa.ProofStream())
+                same = [h.as_bytes() for h in r1] == [bytes(a) for a in roots]
+                flag = torch.tensor([int(ok and same)], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                res["round_trip_and_single_gpu_roots_match"] = bool(flag.item())
+                box["res"] = res
+            except Exception as e:  # reported, never fatal for the headline
+                box["res"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        th = threading.Thread(target=dist_leg, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("STARK_BENCH_DIST_TIMEOUT", "120")))
+        if th.is_alive():
+            out["extra"]["dist_one_codeword_over_all_gpus"] = {"error": "watchdog: distributed leg did not finish"}
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        out["extra"]["dist_one_codeword_over_all_gpus"] = box.get("res")
+
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import coracle as co      # checker used as the CPU baseline leg only
         log_s = 18
@@ -239,7 +305,7 @@ def main():
                                "optimized_port_1core_elems_per_s": (1 << log_s) / t2, "host_cpus": os.cpu_count()}
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     d_cw.free()
     ctx.close()
     if dist is not None:
