@@ -98,6 +98,8 @@ _sig("or_ps_verifier_fiat_shamir", C.c_int, C.c_void_p, u8p)
 _sig("or_fri_commit", C.c_int, u64p, C.c_size_t, C.c_uint32, C.c_uint32, u64p, C.c_void_p, C.c_int,
      u8p, C.POINTER(C.c_uint32), u64p, C.POINTER(C.c_size_t), u64p)
 _sig("or_splitmix_elems", None, C.c_uint64, u64p, C.c_size_t)
+_sig("or_set_threads", None, C.c_int)
+_sig("or_get_threads", C.c_int)
 
 
 # ---------------- helpers ----------------
@@ -247,6 +249,9 @@ def sample(digest):
 
 
 def fri_num_rounds(N, expansion, t): return int(lib.or_fri_num_rounds(N, expansion, t))
+
+
+def set_threads(t): lib.or_set_threads(int(t))
 
 
 def splitmix_elems(seed, n):

@@ -10,6 +10,32 @@
 #include <string.h>
 #include <stdio.h>
 
+/* ------------------------------------------------------------------------------------------
+ * Optional host threading for the "optimized CPU" baseline leg.  Default 1 thread: every
+ * parity test runs the sequential code.  Results are identical for any thread count (disjoint output ranges).
+ * ------------------------------------------------------------------------------------------ */
+#include <pthread.h>
+static int g_threads = 1;
+void or_set_threads(int t) { g_threads = t < 1 ? 1 : (t > 256 ? 256 : t); }
+int or_get_threads(void) { return g_threads; }
+typedef void (*par_fn)(size_t lo, size_t hi, void* arg);
+typedef struct { par_fn fn; void* arg; size_t lo, hi; } par_job;
+static void* par_tramp(void* p) { par_job* j = (par_job*)p; j->fn(j->lo, j->hi, j->arg); return NULL; }
+static void par_for(size_t n, size_t min_chunk, par_fn fn, void* arg) {
+    size_t T = (size_t)g_threads;
+    if (T > n / (min_chunk ? min_chunk : 1)) T = n / (min_chunk ? min_chunk : 1);
+    if (T <= 1) { fn(0, n, arg); return; }
+    pthread_t th[256]; par_job jobs[256];
+    size_t started = 0;
+    for (size_t t = 0; t < T; ++t) {
+        jobs[t].fn = fn; jobs[t].arg = arg; jobs[t].lo = n * t / T; jobs[t].hi = n * (t + 1) / T;
+        if (t + 1 == T) { fn(jobs[t].lo, jobs[t].hi, arg); break; }
+        if (pthread_create(&th[t], NULL, par_tramp, &jobs[t]) != 0) { fn(jobs[t].lo, n, arg); break; }   /* no thread: finish here */
+        ++started;
+    }
+    for (size_t t = 0; t < started; ++t) pthread_join(th[t], NULL);
+}
+
 typedef unsigned __int128 u128;
 
 /* field.rs:15  PRIME = 1 + 407 * 2^119 = 0xcb800000000000000000000000000001 */
@@ -383,22 +409,34 @@ void or_sha256(const uint8_t* in, size_t len, uint8_t out[32]) {
 /* ------------------------------------------------------------------------------------------
  * Merkle (merkle.rs)
  * ------------------------------------------------------------------------------------------ */
+typedef struct { const uint8_t* in; uint8_t* out; } merkle_level_arg;
+static void merkle_level_range(size_t lo, size_t hi, void* p) {
+    merkle_level_arg* a = (merkle_level_arg*)p;
+    for (size_t i = lo; i < hi; ++i) or_blake2b512(a->in + 128 * i, 128, a->out + 64 * i);
+}
 int or_merkle_commit(const uint8_t* leaves, size_t L, uint8_t root[64]) {    /* merkle.rs:35-68 */
     if (L == 0 || (L & (L - 1))) return -1;                                  /* merkle.rs:36 assert */
     uint8_t* hashes = (uint8_t*)malloc(L * 64);                              /* merkle.rs:38 */
     if (!hashes) return -4;
     memcpy(hashes, leaves, L * 64);
     size_t n = L;
+    uint8_t* other = NULL;                                                   /* threaded legs ping-pong between two buffers */
     while (n > 1) {                                                          /* merkle.rs:48 */
-        for (size_t i = 0; i < n / 2; ++i) {                                 /* merkle.rs:51-56: H(left || right) */
-            uint8_t d[64];
-            or_blake2b512(hashes + 128 * i, 128, d);
-            memcpy(hashes + 64 * i, d, 64);
+        if (g_threads > 1 && n >= 4096 && (other || (other = (uint8_t*)malloc(L * 32)) != NULL)) {
+            merkle_level_arg a = {hashes, other};
+            par_for(n / 2, 1024, merkle_level_range, &a);
+            uint8_t* t = hashes; hashes = other; other = t;
+        } else {
+            for (size_t i = 0; i < n / 2; ++i) {                             /* merkle.rs:51-56: H(left || right) */
+                uint8_t d[64];
+                or_blake2b512(hashes + 128 * i, 128, d);
+                memcpy(hashes + 64 * i, d, 64);
+            }
         }
         n /= 2;
     }
     memcpy(root, hashes, 64);                                                /* merkle.rs:62 (L==1: root==leaf) */
-    free(hashes);
+    free(hashes); free(other);
     return 0;
 }
 int or_merkle_open(const uint8_t* leaves, size_t L, size_t index, uint8_t* path, size_t* path_len) { /* merkle.rs:70-108 */
@@ -431,12 +469,18 @@ int or_merkle_verify(const uint8_t root[64], const uint8_t leaf[64], const uint8
     }
     return memcmp(cur, root, 64) == 0 ? 1 : 0;                               /* merkle.rs:153 */
 }
-void or_hash_leaves(const uint64_t* elems, size_t L, uint8_t* out) {         /* G2: Blake2b512(value.to_le_bytes()) */
-    for (size_t i = 0; i < L; ++i) {
+typedef struct { const uint64_t* elems; uint8_t* out; } leaves_arg;
+static void hash_leaves_range(size_t lo, size_t hi, void* p) {
+    leaves_arg* a = (leaves_arg*)p;
+    for (size_t i = lo; i < hi; ++i) {
         uint8_t le[16];
-        for (int k = 0; k < 8; ++k) { le[k] = (uint8_t)(elems[2 * i] >> (8 * k)); le[8 + k] = (uint8_t)(elems[2 * i + 1] >> (8 * k)); }
-        or_blake2b512(le, 16, out + 64 * i);
+        for (int k = 0; k < 8; ++k) { le[k] = (uint8_t)(a->elems[2 * i] >> (8 * k)); le[8 + k] = (uint8_t)(a->elems[2 * i + 1] >> (8 * k)); }
+        or_blake2b512(le, 16, a->out + 64 * i);
     }
+}
+void or_hash_leaves(const uint64_t* elems, size_t L, uint8_t* out) {         /* G2: Blake2b512(value.to_le_bytes()) */
+    leaves_arg a = {elems, out};
+    par_for(L, 2048, hash_leaves_range, &a);
 }
 int or_merkle_commit_elems(const uint64_t* elems, size_t L, uint8_t root[64]) {
     if (L == 0 || (L & (L - 1))) return -1;
@@ -515,18 +559,24 @@ int or_coset_lde(const uint64_t* coeffs, uint32_t log_n, uint32_t log_expansion,
     memset(out + 2 * n, 0, (N - n) * 16);
     return or_ntt(out, log_N, 0);
 }
+typedef struct { const uint64_t* cw; uint64_t* out; size_t L; u128 a, inv2, winv, d0; } fold_arg;
+static void fold_range(size_t lo, size_t hi, void* p) {
+    fold_arg* f = (fold_arg*)p;
+    u128 d = lo ? fp_mul(f->d0, fp_pow(f->winv, (u128)lo)) : f->d0;
+    for (size_t i = lo; i < hi; ++i) {
+        u128 t = fp_mul(f->a, d);
+        u128 x = fp_mul(fp_add(1, t), ld(f->cw + 2 * i)), y = fp_mul(fp_sub(1, t), ld(f->cw + 2 * (f->L / 2 + i)));
+        st(f->out + 2 * i, fp_mul(f->inv2, fp_add(x, y)));
+        d = fp_mul(d, f->winv);
+    }
+}
 int or_fri_fold(const uint64_t* cw, size_t L, const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], uint64_t* out) {
     /* G4: cw'[i] = 2^-1 * ((1 + a/(off*w^i)) * cw[i] + (1 - a/(off*w^i)) * cw[L/2+i]) */
     if (L < 2 || (L & (L - 1))) return -1;
     u128 a = ld(alpha), off = ld(offset), w = ld(omega);
     if (off == 0 || w == 0) return -2;
-    u128 inv2 = fp_inv(2), winv = fp_inv(w), d = fp_inv(off);       /* d_i = 1/(off*w^i) = off^-1 * (w^-1)^i */
-    for (size_t i = 0; i < L / 2; ++i) {
-        u128 t = fp_mul(a, d);
-        u128 x = fp_mul(fp_add(1, t), ld(cw + 2 * i)), y = fp_mul(fp_sub(1, t), ld(cw + 2 * (L / 2 + i)));
-        st(out + 2 * i, fp_mul(inv2, fp_add(x, y)));
-        d = fp_mul(d, winv);
-    }
+    fold_arg fa = {cw, out, L, a, fp_inv(2), fp_inv(w), fp_inv(off)};   /* d_i = 1/(off*w^i) = off^-1 * (w^-1)^i */
+    par_for(L / 2, 2048, fold_range, &fa);
     return 0;
 }
 int or_fri_fold_faithful(const uint64_t* cw, size_t L, const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], uint64_t* out, int use_i320) {

@@ -109,6 +109,9 @@ int or_fri_commit(const uint64_t* codeword, size_t N, uint32_t expansion, uint32
 
 /* deterministic inputs: SplitMix64(seed) -> two u64 -> u128 -> mod p */
 void or_splitmix_elems(uint64_t seed, uint64_t* out, size_t n);
+/* host threads for leaf hashing / Merkle levels / fold (default 1; same results for any count): the all-cores CPU baseline leg */
+void or_set_threads(int t);
+int or_get_threads(void);
 
 #ifdef __cplusplus
 }
