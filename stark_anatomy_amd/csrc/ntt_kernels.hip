@@ -36,7 +36,10 @@ __device__ __forceinline__ fp ntt_load_tw(const fp* __restrict__ tw, uint32_t lo
     return mont_mul(lo, hi);
 }
 
-__global__ __launch_bounds__(256) void k_ntt_pass(NttPassParams p) {
+#ifndef NTT_THREADS
+#define NTT_THREADS 1024
+#endif
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     fp* x = reinterpret_cast<fp*>(lds_raw);
     const uint32_t R = 1u << p.log_r, C = 1u << p.log_c, T = R * C;
@@ -184,7 +187,7 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         const size_t tiles = ((size_t)1 << p.log_tiles) * batch;
         if (tiles > 0x7fffffffu) return hipErrorInvalidValue;
         const size_t lds = pass_lds_bytes(p.log_r, p.log_c, is_final);
-        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(256), lds, s, p);
+        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS), lds, s, p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         consumed += p.log_r;
