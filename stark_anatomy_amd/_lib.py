@@ -25,6 +25,13 @@ if not os.path.exists(SO_PATH):
         f"{SO_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
         "or make -C stark_anatomy_amd/csrc). stark_anatomy_amd has no CPU fallback.")
 
+try:
+    # torch bundles its own HIP runtime.  If libstark_hip.so (linked against /opt/rocm) is loaded first the process ends
+    # up with two runtimes and torch then reports no device; loading torch first makes both share torch's copy.
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 lib = C.CDLL(SO_PATH)
 
 u64p = C.POINTER(C.c_uint64)

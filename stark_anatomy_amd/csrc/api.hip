@@ -362,10 +362,14 @@ static int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_
         uint8_t root[64];
         SHCHK(merkle_root_from_elems(c, cur, L));
         SHCHK(fetch_root(c, root));
+        const bool dbg = getenv("STARK_HIP_DEBUG") != nullptr;     // per-round host timing: callback / enqueue / wait for the root
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         for (uint32_t r = 0; r < R; ++r) {
             memcpy(roots_out + 64 * (size_t)r, root, 64);
             const int32_t want = (r + 1 < R) ? 1 : 0;
             uint64_t alpha_w[2] = {0, 0};
+            const auto t0 = now();
             if (cb(user, r, root, want, alpha_w) != 0) return sh_failf(SH_ECALLBACK, "fri_commit: transcript callback failed in round %u", r);
             if (!want) break;
             const fp alpha = fp_load_host(alpha_w);
@@ -377,9 +381,14 @@ static int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_
             uint32_t K = leaf_subtree_k(ilog2(half));
             void* dig;
             SHCHK(ensure_scratch(c, SCR_DIG_A, (half >> K) * sizeof(digest64), &dig));
+            const auto t1 = now();
             HIPCHK(launch_fold_leaf_subtree(cur, L, 1, nullptr, fp_to_mont(c0), tw_inv, log_N, r, next, (digest64*)dig, K, c->stream));
+            const auto t2 = now();
             SHCHK(reduce_digests(c, (const digest64*)dig, half >> K));
+            const auto t3 = now();
             SHCHK(fetch_root(c, root));
+            if (dbg) fprintf(stderr, "[stark_hip] round %2u L=2^%-2u  cb+c0 %5.1f us | launch fold %5.1f | launch reduce %5.1f | wait root %6.1f\n",
+                             r, ilog2(L), us(t0, t1), us(t1, t2), us(t2, t3), us(t3, now()));
             cur = next; L = half;
             off_inv = fp_mul(off_inv, off_inv);
         }

@@ -34,14 +34,31 @@ __device__ __forceinline__ uint64_t quad_rot(uint64_t v) {
     return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
 }
 
+// 64-bit rotate right as two v_alignbit_b32 on the halves (left to itself the compiler builds the rotates that feed
+// DPP moves from 64-bit shifts and ORs: ~4 instructions each instead of 2, on a chain where every instruction is
+// ~6 cycles of latency).
+template <int N>
+__device__ __forceinline__ uint64_t qrotr(uint64_t v) {
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    if (N == 32) return ((uint64_t)lo << 32) | hi;
+    if (N < 32) {
+        const uint32_t nl = __builtin_amdgcn_alignbit(hi, lo, N), nh = __builtin_amdgcn_alignbit(lo, hi, N);
+        return ((uint64_t)nh << 32) | nl;
+    }
+    const uint32_t nl = __builtin_amdgcn_alignbit(lo, hi, N - 32), nh = __builtin_amdgcn_alignbit(hi, lo, N - 32);
+    return ((uint64_t)nh << 32) | nl;
+}
+
 #define QG(a, b, c, d, x, y)                      \
     do {                                          \
-        a = a + b + (x); d = b2b_rotr(d ^ a, 32); \
-        c = c + d;       b = b2b_rotr(b ^ c, 24); \
-        a = a + b + (y); d = b2b_rotr(d ^ a, 16); \
-        c = c + d;       b = b2b_rotr(b ^ c, 63); \
+        a = a + b + (x); d = qrotr<32>(d ^ a);    \
+        c = c + d;       b = qrotr<24>(b ^ c);    \
+        a = a + b + (y); d = qrotr<16>(d ^ a);    \
+        c = c + d;       b = qrotr<63>(b ^ c);    \
     } while (0)
 
+#define QR_PAIR_U64 18
+#define QR_DIGEST_OFF(d) (((d) >> 1) * QR_PAIR_U64 + ((d) & 1) * 8)
 #define QR_THREADS 512
 #define QR_QUADS (QR_THREADS / 4)
 
@@ -50,7 +67,10 @@ __device__ __forceinline__ uint64_t quad_rot(uint64_t v) {
 // pinned host memory so the host can pick the root up by polling instead of a stream synchronise.
 __global__ __launch_bounds__(QR_THREADS) void k_quad_reduce(const digest64* __restrict__ in, digest64* __restrict__ out, uint32_t log_chunk,
                                                             uint64_t* __restrict__ mailbox, uint32_t seq) {
-    __shared__ __align__(16) uint64_t sm[(512 + 256) * 8];
+    // Level buffers hold digest PAIRS (= one node's 128-byte message) at a stride of 144 bytes: with the natural 128 the
+    // same message word of all 16 quads of a wave falls in one LDS bank (rocprof: SQ_LDS_BANK_CONFLICT = 70 % of
+    // LDS-active cycles); 16 bytes of padding rotate consecutive pairs by 4 banks and keep 16-byte alignment.
+    __shared__ __align__(16) uint64_t sm[(256 + 128) * QR_PAIR_U64];
     const uint32_t tid = threadIdx.x, q = tid & 3, quad = tid >> 2;
     const uint32_t chunk = 1u << log_chunk;
 
@@ -66,30 +86,35 @@ __global__ __launch_bounds__(QR_THREADS) void k_quad_reduce(const digest64* __re
     {
         const uint4* src = reinterpret_cast<const uint4*>(in + ((size_t)blockIdx.x << log_chunk));
         uint4* dst = reinterpret_cast<uint4*>(sm);
-        for (uint32_t i = tid; i < chunk * 4; i += QR_THREADS) dst[i] = src[i];
+        for (uint32_t i = tid; i < chunk * 4; i += QR_THREADS) dst[(QR_DIGEST_OFF(i >> 2) >> 1) + (i & 3)] = src[i];
     }
     __syncthreads();
 
-    uint32_t s_off = 0, d_off = 512 * 8;
+    uint32_t s_off = 0, d_off = 256 * QR_PAIR_U64;
 #pragma unroll 1
     for (uint32_t n = chunk >> 1; n >= 1; n >>= 1) {
 #pragma unroll 1
         for (uint32_t node = quad; node < n; node += QR_QUADS) {
-            const unsigned char* m = reinterpret_cast<const unsigned char*>(sm + s_off + node * 16);
+            const unsigned char* m = reinterpret_cast<const unsigned char*>(sm + s_off + node * QR_PAIR_U64);
             uint64_t a = a0, b = b0, c = c0, d = d0;
+            uint64_t mw[12][4];                                          // all 48 message words up front: LDS latency paid once
 #pragma unroll
             for (int r = 0; r < 12; ++r) {
                 const uint32_t sg = sig[r];
-                const uint64_t x0 = *reinterpret_cast<const uint64_t*>(m + (sg & 0xff));
-                const uint64_t y0 = *reinterpret_cast<const uint64_t*>(m + ((sg >> 8) & 0xff));
-                const uint64_t x1 = *reinterpret_cast<const uint64_t*>(m + ((sg >> 16) & 0xff));
-                const uint64_t y1 = *reinterpret_cast<const uint64_t*>(m + (sg >> 24));
-                QG(a, b, c, d, x0, y0);                                   // column step
+                mw[r][0] = *reinterpret_cast<const uint64_t*>(m + (sg & 0xff));
+                mw[r][1] = *reinterpret_cast<const uint64_t*>(m + ((sg >> 8) & 0xff));
+                mw[r][2] = *reinterpret_cast<const uint64_t*>(m + ((sg >> 16) & 0xff));
+                mw[r][3] = *reinterpret_cast<const uint64_t*>(m + (sg >> 24));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                QG(a, b, c, d, mw[r][0], mw[r][1]);                       // column step
                 b = quad_rot<1>(b); c = quad_rot<2>(c); d = quad_rot<3>(d);
-                QG(a, b, c, d, x1, y1);                                   // diagonal step
+                QG(a, b, c, d, mw[r][2], mw[r][3]);                       // diagonal step
                 b = quad_rot<3>(b); c = quad_rot<2>(c); d = quad_rot<1>(d);
             }
-            uint64_t* o = sm + d_off + node * 8;
+            uint64_t* o = sm + d_off + QR_DIGEST_OFF(node);
             o[q] = a0 ^ a ^ c;
             o[4 + q] = b0 ^ b ^ d;
         }
