@@ -39,6 +39,41 @@ __device__ __forceinline__ fp ntt_load_tw(const fp* __restrict__ tw, uint32_t lo
 #ifndef NTT_THREADS
 #define NTT_THREADS 1024
 #endif
+#ifndef NTT_RADIX_LOG
+#define NTT_RADIX_LOG 2
+#endif
+
+// Levels lo+S-1 … lo of the in-place DIF over the row index of an R x C tile in LDS (row stride rs), S levels per LDS
+// round trip: a work item is the 2^S rows that differ in row bits [lo, lo+S) at one column; it is read once, takes
+// its S butterfly levels in registers and is written back to the same addresses (no barrier inside).
+// Level with pair distance 2^h multiplies the difference by w_R^(j << (log_r-1-h)), j = row mod 2^h (none for h = 0).
+template <int S>
+__device__ __forceinline__ void ntt_levels(fp* __restrict__ x, const fp* __restrict__ twr, uint32_t rs, uint32_t log_r, uint32_t log_c,
+                                           uint32_t lo, uint32_t T, uint32_t tid, uint32_t nthreads) {
+    const uint32_t C = 1u << log_c;
+    for (uint32_t w = tid; w < (T >> S); w += nthreads) {
+        const uint32_t c = w & (C - 1), q = w >> log_c;
+        const uint32_t r_low = q & ((1u << lo) - 1), r0 = ((q >> lo) << (lo + S)) | r_low;
+        fp v[1 << S];
+#pragma unroll
+        for (int e = 0; e < (1 << S); ++e) v[e] = x[(r0 + ((uint32_t)e << lo)) * rs + c];
+#pragma unroll
+        for (int s = S - 1; s >= 0; --s) {
+            const uint32_t sh = log_r - 1 - (lo + s);
+#pragma unroll
+            for (int e = 0; e < (1 << S); ++e) {
+                if (e & (1 << s)) continue;
+                const fp u = v[e], t = v[e | (1 << s)];
+                v[e] = fp_add(u, t);
+                fp d = fp_sub(u, t);
+                if (lo + s) d = mont_mul(d, twr[(r_low + ((uint32_t)(e & ((1 << s) - 1)) << lo)) << sh]);
+                v[e | (1 << s)] = d;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < (1 << S); ++e) x[(r0 + ((uint32_t)e << lo)) * rs + c] = v[e];
+    }
+}
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     fp* x = reinterpret_cast<fp*>(lds_raw);
@@ -79,20 +114,22 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams p) {
     }
     __syncthreads();
 
-    // log2(R) decimation-in-frequency levels in LDS
-#pragma unroll 1
-    for (int lh = (int)p.log_r - 1; lh >= 0; --lh) {
-        const uint32_t half = 1u << lh;
-        for (uint32_t b = tid; b < (T >> 1); b += blockDim.x) {
-            const uint32_t c = b & (C - 1), q = b >> p.log_c;
-            const uint32_t j = q & (half - 1), i = ((q >> lh) << (lh + 1)) | j;
-            fp u = x[i * rs + c], v = x[(i + half) * rs + c];
-            x[i * rs + c] = fp_add(u, v);
-            fp d = fp_sub(u, v);
-            if (lh) d = mont_mul(d, twr[j << (p.log_r - 1 - lh)]);
-            x[(i + half) * rs + c] = d;
+    // log2(R) decimation-in-frequency levels, NTT_RADIX_LOG at a time in registers: one LDS round trip and one
+    // barrier per group of levels instead of per level.
+    for (uint32_t hb = p.log_r; hb > 0;) {
+        const uint32_t S = hb < NTT_RADIX_LOG ? hb : NTT_RADIX_LOG, lo = hb - S;
+        switch (S) {
+            case 1: ntt_levels<1>(x, twr, rs, p.log_r, p.log_c, lo, T, tid, blockDim.x); break;
+            case 2: ntt_levels<2>(x, twr, rs, p.log_r, p.log_c, lo, T, tid, blockDim.x); break;
+#if NTT_RADIX_LOG >= 3
+            case 3: ntt_levels<3>(x, twr, rs, p.log_r, p.log_c, lo, T, tid, blockDim.x); break;
+#endif
+#if NTT_RADIX_LOG >= 4
+            case 4: ntt_levels<4>(x, twr, rs, p.log_r, p.log_c, lo, T, tid, blockDim.x); break;
+#endif
         }
         __syncthreads();
+        hb = lo;
     }
 
     if (!p.is_final) {
