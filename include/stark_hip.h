@@ -164,6 +164,9 @@ int32_t sh_proofstream_free(sh_proofstream* ps);
 int32_t sh_proofstream_push_json(sh_proofstream* ps, const uint8_t* json, size_t len); /* push, :25-27 (any S) */
 int32_t sh_proofstream_push_merkle_root(sh_proofstream* ps, const uint8_t root[64]);
 int32_t sh_proofstream_push_codeword(sh_proofstream* ps, const uint64_t* elems, size_t n);
+/* query-phase items (G9): {"Leaves":[dec,...]} and {"Path":[{"inner":[..]},...]} (Vec<MerkleHash>, merkle.rs:9-13) */
+int32_t sh_proofstream_push_leaves(sh_proofstream* ps, const uint64_t* elems, size_t n);
+int32_t sh_proofstream_push_path(sh_proofstream* ps, const uint8_t* digests, size_t n);
 int32_t sh_proofstream_len(sh_proofstream* ps, size_t* n_items, size_t* read_index);
 int32_t sh_proofstream_pull(sh_proofstream* ps, const uint8_t** json, size_t* len);    /* pull, :29-36; SH_EBOUNDS */
 int32_t sh_proofstream_serialize(sh_proofstream* ps, uint8_t* out, size_t cap, size_t* needed); /* :38-40 */
@@ -176,6 +179,31 @@ int32_t sh_fri_commit_proofstream(sh_ctx* ctx, const uint64_t* codeword, size_t 
                                   sh_proofstream* ps, uint8_t* roots_out, uint64_t* last_codeword_out, size_t* last_len);
 int32_t sh_dev_fri_commit_proofstream(sh_ctx* ctx, const uint64_t* d_codeword, size_t N, const sh_fri_params* params,
                                       sh_proofstream* ps, uint8_t* roots_out, uint64_t* last_codeword_out, size_t* last_len);
+
+/* ---------------- FRI query phase, prover and verifier ----------------
+ * Not in the reference (it stops at MerkleTree::open/verify and ProofStream); defined after the upstream tutorial the
+ * reference follows, with the reference's own primitives: SHA-256 Fiat-Shamir (proof_stream.rs:51-64), Blake2b Merkle
+ * paths in MerkleTree::open order (merkle.rs:104-107), checked like is_leaf_in_tree (merkle.rs:114-154).
+ *
+ * sh_merkle_open_batch: `n_idx` openings of one tree in one pass — all levels are built once on the GPU and the
+ * siblings gathered; paths[q] = n-th path, log2(L)·64 bytes each, leaf sibling first.  SH_EBOUNDS / SH_EINVAL as
+ * sh_merkle_open.  The _elems form hashes field elements to leaves first (G2). */
+int32_t sh_merkle_open_batch(sh_ctx* ctx, const uint8_t* leaves, size_t L, const uint64_t* indices, size_t n_idx, uint8_t* paths);
+int32_t sh_dev_merkle_open_elems_batch(sh_ctx* ctx, const uint64_t* d_elems, size_t L, const uint64_t* indices, size_t n_idx, uint8_t* paths);
+/* G10: `number` indices in [0,size) with pairwise distinct residues mod reduced_size, from Blake2b512(seed || counter_le64). Host only. */
+int32_t sh_fri_sample_indices(const uint8_t seed[32], uint64_t size, uint64_t reduced_size, uint32_t number, uint64_t* out);
+/* G11: commit (as sh_fri_commit_proofstream) followed by the query phase.  Items pushed after the last codeword, per
+ * round r < R-1: t x {"Leaves":[cw_r[a],cw_r[b],cw_(r+1)[a]]}, then per test the paths of a, b = a + L_r/2 (tree r) and
+ * a (tree r+1); a = top_index mod L_r/2.  top_level_indices (t entries, may be NULL) / *n_indices (0 when R < 2). */
+int32_t sh_fri_prove(sh_ctx* ctx, const uint64_t* codeword, size_t N, const sh_fri_params* params, sh_proofstream* stream,
+                     uint64_t* top_level_indices, size_t* n_indices);
+int32_t sh_dev_fri_prove(sh_ctx* ctx, const uint64_t* d_codeword, size_t N, const sh_fri_params* params, sh_proofstream* stream,
+                         uint64_t* top_level_indices, size_t* n_indices);
+/* G12: verifier, host only; consumes the stream from its read index.  *accepted = 1 iff the roots, the last codeword
+ * (root match, degree < L_last/expansion), every colinearity test and every authentication path check out; on 0,
+ * sh_last_error() names the failed check.  Returns SH_OK unless the arguments themselves are invalid. */
+int32_t sh_fri_verify(sh_proofstream* stream, size_t N, const sh_fri_params* params, int32_t* accepted,
+                      uint64_t* top_level_indices, size_t* n_indices);
 
 /* Batch of B independent commits of equal length N (BASELINE config 4: 1024 x 2^14), codewords back to back
  * (B*N elements).  Rounds run in lock step: every kernel covers all B codewords, each codeword has its own

@@ -226,6 +226,135 @@ def fri_commit(codeword, expansion, num_colinearity_tests, offset, ps):   # SURV
     return roots, alphas, cw
 
 
+# ---- query phase, prover, verifier (G9-G12, after the upstream tutorial's fri.py) ----
+def item_leaves(a, b, c): return {"Leaves": [int(a), int(b), int(c)]}                       # G9
+def item_path(path): return {"Path": [{"inner": list(h)} for h in path]}                   # G9: Vec<MerkleHash>
+
+
+def sample_index(byte_array, size):                              # G10 (tutorial: sample_index)
+    acc = 0
+    for b in byte_array:
+        acc = (acc << 8) ^ int(b)
+    return acc % size
+
+
+def sample_indices(seed, size, reduced_size, number):            # G10 (tutorial: sample_indices; counter as u64 LE)
+    assert number <= reduced_size, "cannot sample more indices than available in last codeword"
+    indices, reduced_indices, counter = [], [], 0
+    while len(indices) < number:
+        index = sample_index(blake2b512(bytes(seed) + counter.to_bytes(8, "little")), size)
+        reduced_index = index % reduced_size
+        counter += 1
+        if reduced_index not in reduced_indices:
+            indices.append(index); reduced_indices.append(reduced_index)
+    return indices
+
+
+def fri_commit_codewords(codeword, expansion, num_colinearity_tests, offset, ps):
+    """fri_commit, keeping every round's codeword (tutorial: commit returns `codewords`)"""
+    N = len(codeword)
+    R = fri_num_rounds(N, expansion, num_colinearity_tests)
+    omega = root_of_unity(N.bit_length() - 1)
+    cw = list(codeword); codewords = []
+    for r in range(R):
+        ps.push(item_root(merkle_commit_elems(cw)))
+        codewords.append(cw)
+        if r == R - 1:
+            break
+        alpha = sample(ps.prover_fiat_shamir())
+        cw = fri_fold(cw, alpha, offset, omega)
+        omega = omega * omega % P; offset = offset * offset % P
+    ps.push(item_codeword(cw))
+    if R == 0:
+        codewords.append(cw)
+    return codewords
+
+
+def fri_query(current, nxt, c_indices, ps):                      # G11 (tutorial: query)
+    a_indices = list(c_indices)
+    b_indices = [i + len(current) // 2 for i in c_indices]
+    for s in range(len(c_indices)):
+        ps.push(item_leaves(current[a_indices[s]], current[b_indices[s]], nxt[c_indices[s]]))
+    cur_leaves, nxt_leaves = hash_leaves(current), hash_leaves(nxt)
+    for s in range(len(c_indices)):
+        ps.push(item_path(merkle_open(cur_leaves, a_indices[s])))
+        ps.push(item_path(merkle_open(cur_leaves, b_indices[s])))
+        ps.push(item_path(merkle_open(nxt_leaves, c_indices[s])))
+    return a_indices + b_indices
+
+
+def fri_prove(codeword, expansion, num_colinearity_tests, offset, ps):     # G11 (tutorial: prove)
+    codewords = fri_commit_codewords(codeword, expansion, num_colinearity_tests, offset, ps)
+    if len(codewords) < 2:
+        return []
+    top = sample_indices(ps.prover_fiat_shamir(), len(codewords[1]), len(codewords[-1]), num_colinearity_tests)
+    indices = list(top)
+    for i in range(len(codewords) - 1):
+        indices = [index % (len(codewords[i]) // 2) for index in indices]
+        fri_query(codewords[i], codewords[i + 1], indices, ps)
+    return top
+
+
+def fri_verify(ps, N, expansion, num_colinearity_tests, offset):           # G12 (tutorial: verify); returns (ok, reason)
+    R = fri_num_rounds(N, expansion, num_colinearity_tests)
+    omega = root_of_unity(N.bit_length() - 1)
+    try:
+        roots, alphas = [], []
+        for r in range(R):
+            roots.append(bytes(ps.pull()["MerkleRoot"]["inner"]))
+            if r < R - 1:
+                alphas.append(sample(ps.verifier_fiat_shamir()))
+        last = [int(v) for v in ps.pull()["Codeword"]]
+    except (KeyError, TypeError, IndexError):
+        return False, "malformed commit items"
+    L_last = N >> max(R - 1, 0)
+    if len(last) != L_last or any(not (0 <= v < P) for v in last):
+        return False, "last codeword malformed"
+    if R == 0:
+        return True, ""
+    if merkle_commit_elems(last) != roots[-1]:
+        return False, "last codeword is not well formed"
+    # degree of the interpolant through (offset_last * omega_last^i, last[i]): coefficients by naive inverse DFT, unscaled
+    off_last = pow(offset, 1 << (R - 1), P)
+    coeffs = [fp_div(c, pow(off_last, j, P)) for j, c in enumerate(ntt_naive(last, inverse=True))]
+    degree = max((j for j, c in enumerate(coeffs) if c), default=-1)
+    if degree > max(L_last // expansion, 1) - 1:
+        return False, "last codeword does not correspond to polynomial of low enough degree"
+    if R < 2:
+        return True, ""
+    top = sample_indices(ps.verifier_fiat_shamir(), N // 2, L_last, num_colinearity_tests)
+    t = num_colinearity_tests
+    for r in range(R - 1):
+        L = N >> r
+        c_indices = [i % (L // 2) for i in top]
+        try:
+            triples = [ps.pull()["Leaves"] for _ in range(t)]
+            for s in range(t):
+                ay, by, cy = triples[s]
+                ax = fp_mul(offset, pow(omega, c_indices[s], P)); bx = fp_mul(offset, pow(omega, c_indices[s] + L // 2, P)); cx = alphas[r]
+                # colinearity of (ax,ay), (bx,by), (cx,cy): cross product of differences
+                if fp_mul(fp_sub(by, ay), fp_sub(cx, ax)) != fp_mul(fp_sub(cy, ay), fp_sub(bx, ax)):
+                    return False, "colinearity check failure"
+            for s in range(t):
+                pa = [bytes(h["inner"]) for h in ps.pull()["Path"]]
+                pb = [bytes(h["inner"]) for h in ps.pull()["Path"]]
+                pc = [bytes(h["inner"]) for h in ps.pull()["Path"]]
+                ay, by, cy = triples[s]
+                depth = L.bit_length() - 1
+                if len(pa) != depth or len(pb) != depth or len(pc) != depth - 1:
+                    return False, "path length"
+                if not merkle_verify(roots[r], hash_leaf(ay), pa, c_indices[s]):
+                    return False, "merkle authentication path verification fails for aa"
+                if not merkle_verify(roots[r], hash_leaf(by), pb, c_indices[s] + L // 2):
+                    return False, "merkle authentication path verification fails for bb"
+                if not merkle_verify(roots[r + 1], hash_leaf(cy), pc, c_indices[s]):
+                    return False, "merkle authentication path verification fails for cc"
+        except (KeyError, TypeError, IndexError, ValueError):
+            return False, "malformed query items"
+        omega = omega * omega % P; offset = offset * offset % P
+    return True, ""
+
+
 def splitmix_elems(seed, n):                                     # SURVEY §8d
     s = seed & MASK64; out = []
     for _ in range(n):

@@ -107,6 +107,14 @@ _PROTOS = {
     "sh_dev_fri_commit_proofstream": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.POINTER(FriParams), ps_t, u8p, u64p, szp]),
     "sh_fri_commit_batch": (C.c_int32, [ctx_t, u64p, C.c_size_t, C.c_size_t, C.POINTER(FriParams), C.POINTER(ps_t), u8p, u64p, szp]),
     "sh_dev_fri_commit_batch": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(FriParams), C.POINTER(ps_t), u8p, u64p, szp]),
+    "sh_proofstream_push_leaves": (C.c_int32, [ps_t, u64p, C.c_size_t]),
+    "sh_proofstream_push_path": (C.c_int32, [ps_t, u8p, C.c_size_t]),
+    "sh_merkle_open_batch": (C.c_int32, [ctx_t, u8p, C.c_size_t, u64p, C.c_size_t, u8p]),
+    "sh_dev_merkle_open_elems_batch": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, u64p, C.c_size_t, u8p]),
+    "sh_fri_sample_indices": (C.c_int32, [u8p, C.c_uint64, C.c_uint64, C.c_uint32, u64p]),
+    "sh_fri_prove": (C.c_int32, [ctx_t, u64p, C.c_size_t, C.POINTER(FriParams), ps_t, u64p, szp]),
+    "sh_dev_fri_prove": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.POINTER(FriParams), ps_t, u64p, szp]),
+    "sh_fri_verify": (C.c_int32, [ps_t, C.c_size_t, C.POINTER(FriParams), C.POINTER(C.c_int32), u64p, szp]),
     "sh_sha256": (C.c_int32, [C.c_char_p, C.c_size_t, u8p]),
     "sh_blake2b512": (C.c_int32, [C.c_char_p, C.c_size_t, u8p]),
     "sh_merkle_verify": (C.c_int32, [u8p, u8p, u8p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int32)]),

@@ -345,6 +345,40 @@ int32_t sh_proofstream_push_codeword(sh_proofstream* ps, const uint64_t* elems, 
     ps->items.push_back(std::move(s));
     return SH_OK;
 }
+// Query-phase items: {"Leaves":[a,b,c]} — the three codeword values of one colinearity test — and
+// {"Path":[{"inner":[..]},..]} — a Merkle authentication path, Vec<MerkleHash> as serde writes it (merkle.rs:9-13).
+int32_t sh_proofstream_push_leaves(sh_proofstream* ps, const uint64_t* elems, size_t n) {
+    if (!ps || (!elems && n)) return sh_fail(SH_EINVAL, "sh_proofstream_push_leaves: null pointer");
+    std::string s(11 + n * 40 + 2, '\0');
+    char* buf = &s[0];
+    size_t o = 11;
+    memcpy(buf, "{\"Leaves\":[", 11);
+    for (size_t i = 0; i < n; ++i) {
+        if (i) buf[o++] = ',';
+        o += put_u128_dec(buf + o, ((unsigned __int128)elems[2 * i + 1] << 64) | elems[2 * i]);
+    }
+    buf[o++] = ']'; buf[o++] = '}';
+    s.resize(o);
+    ps->items.push_back(std::move(s));
+    return SH_OK;
+}
+int32_t sh_proofstream_push_path(sh_proofstream* ps, const uint8_t* digests, size_t n) {
+    if (!ps || (!digests && n)) return sh_fail(SH_EINVAL, "sh_proofstream_push_path: null pointer");
+    std::string s(9 + n * (10 + 64 * 4 + 3) + 2, '\0');
+    char* buf = &s[0];
+    size_t o = 9;
+    memcpy(buf, "{\"Path\":[", 9);
+    for (size_t k = 0; k < n; ++k) {
+        if (k) buf[o++] = ',';
+        memcpy(buf + o, "{\"inner\":[", 10); o += 10;
+        for (int i = 0; i < 64; ++i) { if (i) buf[o++] = ','; o += put_u64_dec(buf + o, digests[64 * k + i]); }
+        buf[o++] = ']'; buf[o++] = '}';
+    }
+    buf[o++] = ']'; buf[o++] = '}';
+    s.resize(o);
+    ps->items.push_back(std::move(s));
+    return SH_OK;
+}
 int32_t sh_proofstream_len(sh_proofstream* ps, size_t* n_items, size_t* read_index) {
     if (!ps) return sh_fail(SH_EINVAL, "sh_proofstream_len: null pointer");
     if (n_items) *n_items = ps->items.size();
@@ -421,3 +455,65 @@ int32_t sh_proofstream_verifier_fiat_shamir(sh_proofstream* ps, uint8_t out[32])
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ typed item parsers for the verifier (internal)
+namespace {
+struct ItemParse {
+    const uint8_t* p; const uint8_t* end;
+    bool lit(const char* t) { size_t n = strlen(t); if ((size_t)(end - p) < n || memcmp(p, t, n)) return false; p += n; return true; }
+    bool u128(unsigned __int128* v) {                         // bare decimal, no sign, no leading zeros except "0", < 2^128
+        if (p >= end || *p < '0' || *p > '9') return false;
+        if (*p == '0' && p + 1 < end && p[1] >= '0' && p[1] <= '9') return false;
+        unsigned __int128 acc = 0;
+        const unsigned __int128 lim = ~(unsigned __int128)0;
+        while (p < end && *p >= '0' && *p <= '9') {
+            const unsigned d = (unsigned)(*p - '0');
+            if (acc > (lim - d) / 10) return false;
+            acc = acc * 10 + d; ++p;
+        }
+        *v = acc;
+        return true;
+    }
+    bool hash(uint8_t out[64]) {                              // {"inner":[b0,...,b63]}
+        if (!lit("{\"inner\":[")) return false;
+        for (int i = 0; i < 64; ++i) {
+            if (i && !lit(",")) return false;
+            unsigned __int128 v;
+            if (!u128(&v) || v > 255) return false;
+            out[i] = (uint8_t)v;
+        }
+        return lit("]}");
+    }
+};
+}  // namespace
+
+bool host_parse_merkle_root(const uint8_t* json, size_t len, uint8_t out[64]) {
+    ItemParse ip{json, json + len};
+    return ip.lit("{\"MerkleRoot\":") && ip.hash(out) && ip.lit("}") && ip.p == ip.end;
+}
+bool host_parse_elems(const uint8_t* json, size_t len, const char* tag, std::vector<uint64_t>* out) {   // {"<tag>":[dec,...]}
+    ItemParse ip{json, json + len};
+    out->clear();
+    if (!ip.lit("{\"") || !ip.lit(tag) || !ip.lit("\":[")) return false;
+    if (ip.lit("]")) return ip.lit("}") && ip.p == ip.end;
+    for (;;) {
+        unsigned __int128 v;
+        if (!ip.u128(&v)) return false;
+        out->push_back((uint64_t)v); out->push_back((uint64_t)(v >> 64));
+        if (ip.lit(",")) continue;
+        return ip.lit("]}") && ip.p == ip.end;
+    }
+}
+bool host_parse_path(const uint8_t* json, size_t len, std::vector<uint8_t>* out) {                      // {"Path":[{"inner":[..]},...]}
+    ItemParse ip{json, json + len};
+    out->clear();
+    if (!ip.lit("{\"Path\":[")) return false;
+    if (ip.lit("]")) return ip.lit("}") && ip.p == ip.end;
+    for (;;) {
+        uint8_t h[64];
+        if (!ip.hash(h)) return false;
+        out->insert(out->end(), h, h + 64);
+        if (ip.lit(",")) continue;
+        return ip.lit("]}") && ip.p == ip.end;
+    }
+}

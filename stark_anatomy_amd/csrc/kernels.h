@@ -25,6 +25,8 @@ void ntt_make_plan(uint32_t log_n, NttPlan* plan);
 // `data` is transformed in place; `scratch` holds n elements.
 // `batch` contiguous transforms of 2^plan.log_n elements each; `scratch` holds as many elements as `data`.
 hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s);
+hipError_t launch_gather_paths(const digest64* levels, size_t L, const uint64_t* d_index, size_t n_idx, digest64* out, hipStream_t s);
+hipError_t launch_gather_elems(const fp* src, const uint64_t* d_index, size_t n, fp* out, hipStream_t s);
 hipError_t launch_scale_powers(fp* data, size_t count, fp start_mont, fp base, hipStream_t s);
 hipError_t launch_twiddle_scale(fp* data, size_t rows, uint32_t log_cols, uint64_t row0, uint64_t col0, const fp* tw, uint32_t log_n, hipStream_t s);
 // out[j] = j < n ? coeffs[j]·offset^j : 0   for j < N  (coset pre-scale + zero pad, G7)

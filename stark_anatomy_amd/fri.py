@@ -40,6 +40,14 @@ def fold(codeword, alpha, offset, omega, ctx=None):
     return out
 
 
+def sample_indices(seed, size, reduced_size, number):
+    """G10: `number` indices in [0,size) with distinct residues mod reduced_size from a 32-byte seed (host)."""
+    d = np.frombuffer(bytes(seed), dtype=np.uint8).copy()
+    out = np.zeros(max(number, 1), dtype=np.uint64)
+    check(lib.sh_fri_sample_indices(_u8p(d), size, reduced_size, number, _u64p(out)))
+    return [int(v) for v in out[:number]]
+
+
 class Fri:
     def __init__(self, offset=GENERATOR, omega=None, domain_length=None, expansion_factor=4, num_colinearity_tests=17, ctx=None):
         self.offset = offset.value() if isinstance(offset, FieldElement) else int(offset)
@@ -83,6 +91,31 @@ class Fri:
                                                _u8p(roots), _u64p(last), C.byref(last_len))
         check(rc)
         return [MerkleHash(roots[i].tobytes()) for i in range(R)], last[:last_len.value]
+
+    def prove(self, codeword, proof_stream):
+        """commit + query phase (sh_fri_prove).  Returns the top-level test indices."""
+        N = self.domain_length
+        top = np.zeros(max(self.num_colinearity_tests, 1), dtype=np.uint64)
+        n_top = C.c_size_t(0)
+        p = self._params()
+        if isinstance(codeword, (list, tuple, np.ndarray)):
+            cw = elems_to_array(codeword)
+            assert cw.shape[0] == N, "initial codeword length does not match length of initial codeword"
+            rc = lib.sh_fri_prove(self.ctx.handle, _u64p(cw), N, C.byref(p), proof_stream.handle, _u64p(top), C.byref(n_top))
+        else:
+            rc = lib.sh_dev_fri_prove(self.ctx.handle, device_ptr(codeword), N, C.byref(p), proof_stream.handle, _u64p(top), C.byref(n_top))
+        check(rc)
+        return [int(v) for v in top[:n_top.value]]
+
+    def verify(self, proof_stream):
+        """host-side verifier (sh_fri_verify; G12) reading `proof_stream` from its read index.
+        Returns (accepted, reason): reason names the first failed check."""
+        ok = C.c_int32(0)
+        top = np.zeros(max(self.num_colinearity_tests, 1), dtype=np.uint64)
+        n_top = C.c_size_t(0)
+        p = self._params()
+        check(lib.sh_fri_verify(proof_stream.handle, self.domain_length, C.byref(p), C.byref(ok), _u64p(top), C.byref(n_top)))
+        return bool(ok.value), ("" if ok.value else lib.sh_last_error().decode(errors="replace"))
 
     def commit_batch(self, codewords, proof_streams):
         """B independent commits in lock step (sh_fri_commit_batch).  `codewords`: host array of shape (B, N, 2) /

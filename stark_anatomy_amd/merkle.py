@@ -63,6 +63,19 @@ class MerkleTree:
         check(rc)
         return [MerkleHash(path[i].tobytes()) for i in range(n.value)]
 
+    def open_batch(self, indices):
+        """many openings of this tree in one GPU pass (levels built once)"""
+        L = self._leaves.shape[0]
+        idx = np.asarray(list(indices), dtype=np.uint64)
+        assert all(int(i) < L for i in idx), "assertion failed: index < self.leaves.len()"      # merkle.rs:75
+        depth = L.bit_length() - 1
+        out = np.zeros((max(len(idx), 1), max(depth, 1), 64), dtype=np.uint8)
+        rc = lib.sh_merkle_open_batch(self._ctx.handle, _u8p(self._leaves), L, _u64p(idx), len(idx), _u8p(out))
+        if rc == _lib.SH_EBOUNDS:
+            raise IndexError(lib.sh_last_error().decode())
+        check(rc)
+        return [[MerkleHash(out[q, l].tobytes()) for l in range(depth)] for q in range(len(idx))]
+
     def verify(self, leaf, path, index):                      # merkle.rs:110-112
         return self.is_leaf_in_tree(self.root, leaf, path, index)
 

@@ -30,7 +30,8 @@ class SerializationError(ProofStreamError):
 
 
 class ProofItem:
-    """enum ProofItem { MerkleRoot(MerkleHash), Codeword(Vec<u128>) } — serde externally tagged."""
+    """enum ProofItem { MerkleRoot(MerkleHash), Codeword(Vec<u128>), Leaves(Vec<u128>), Path(Vec<MerkleHash>) } — serde
+    externally tagged (G6; Leaves and Path are the query-phase items, G9)."""
 
     def __init__(self, kind, payload):
         self.kind, self.payload = kind, payload
@@ -39,17 +40,27 @@ class ProofItem:
     def MerkleRoot(cls, h): return cls("MerkleRoot", h if isinstance(h, MerkleHash) else MerkleHash(h))
     @classmethod
     def Codeword(cls, values): return cls("Codeword", elems_to_array(values))
+    @classmethod
+    def Leaves(cls, values): return cls("Leaves", elems_to_array(values))
+    @classmethod
+    def Path(cls, hashes): return cls("Path", [h if isinstance(h, MerkleHash) else MerkleHash(h) for h in hashes])
 
     def __eq__(self, o):
         if not isinstance(o, ProofItem) or o.kind != self.kind:
             return False
-        return (self.payload == o.payload) if self.kind == "MerkleRoot" else bool((self.payload == o.payload).all())
+        if self.kind in ("MerkleRoot", "Path"):
+            return self.payload == o.payload
+        return self.payload.shape == o.payload.shape and bool((self.payload == o.payload).all())
 
     @classmethod
     def from_json(cls, text):
         obj = json.loads(text)
         if "MerkleRoot" in obj:
             return cls.MerkleRoot(bytes(obj["MerkleRoot"]["inner"]))
+        if "Leaves" in obj:
+            return cls.Leaves(obj["Leaves"])
+        if "Path" in obj:
+            return cls.Path([bytes(h["inner"]) for h in obj["Path"]])
         return cls.Codeword(obj["Codeword"])
 
 
@@ -76,8 +87,13 @@ class ProofStream:
             if item.kind == "MerkleRoot":
                 r = np.frombuffer(item.payload.as_bytes(), dtype=np.uint8).copy()
                 check(lib.sh_proofstream_push_merkle_root(self.handle, _u8p(r)))
-            else:
+            elif item.kind == "Codeword":
                 check(lib.sh_proofstream_push_codeword(self.handle, _u64p(item.payload), item.payload.shape[0]))
+            elif item.kind == "Leaves":
+                check(lib.sh_proofstream_push_leaves(self.handle, _u64p(item.payload), item.payload.shape[0]))
+            else:
+                d = np.frombuffer(b"".join(h.as_bytes() for h in item.payload), dtype=np.uint8).copy() if item.payload else np.zeros(1, np.uint8)
+                check(lib.sh_proofstream_push_path(self.handle, _u8p(d), len(item.payload)))
             return
         js = _to_json(item).encode()
         check(lib.sh_proofstream_push_json(self.handle, js, len(js)))

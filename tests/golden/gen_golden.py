@@ -122,6 +122,25 @@ def main():
             obj["stream"] = ser.decode()
         dump(name, obj)
 
+    # ---- C1 prove + verify (G9-G12): n = 256 coefficients (seed 1) -> LDE -> N = 2^10 codeword -> full proof ----
+    for name, log_n, seed in (("fri_prove_c1.json", 8, 1), ("fri_prove_n4096.json", 10, 7)):
+        c = po.splitmix_elems(seed, 1 << log_n)
+        cw = po.coset_lde(c, 2, G)
+        ps = po.ProofStream()
+        top = po.fri_prove(cw, 4, 17, G, ps)
+        ser = ps.serialize()
+        ok, why = po.fri_verify(po.ProofStream.deserialize(ser), len(cw), 4, 17, G)
+        assert ok, why
+        obj = {"log_n": log_n, "seed": seed, "N": len(cw), "expansion": 4, "num_colinearity_tests": 17, "offset": str(G),
+               "top_level_indices": top, "num_items": len(ps.items), "stream_sha256": hashlib.sha256(ser).hexdigest(),
+               "stream_len": len(ser), "accepted": ok}
+        if log_n == 8:
+            obj["stream"] = ser.decode()
+        dump(name, obj)
+    seed32 = bytes(range(32))
+    dump("sample_indices.json", [{"seed": seed32.hex(), "size": sz, "reduced_size": rs, "number": k, "indices": po.sample_indices(seed32, sz, rs, k)}
+                                 for sz, rs, k in ((512, 128, 17), (1 << 23, 64, 40), (8, 8, 8), (1 << 40, 1 << 20, 3))])
+
     # ---- C2: n = 2^16 coefficients -> LDE N = 2^18 -> Merkle root (seed 2) ----
     c = po.splitmix_elems(2, 1 << 16)
     y = po.coset_lde(c, 2, G)
