@@ -922,7 +922,7 @@ static int32_t fri_prove_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_p
     const uint32_t t = prm->num_colinearity_tests;
     const uint32_t R = sh_fri_num_rounds(N, prm->expansion, t);
     std::vector<uint8_t> roots((size_t)(R ? R : 1) * 64);
-    std::vector<uint64_t> last(2 * N);
+    std::vector<uint64_t> last(2 * (N >> (R ? R - 1 : 0)));          // the last codeword only (N/2^(R-1) elements)
     size_t last_len = 0;
     std::vector<const fp*> cws;
     PsCbState st{ps};
