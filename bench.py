@@ -226,6 +226,27 @@ def main():
         extra[f"fri_commit_2^{other}_elems_per_s"] = world * (1 << other) * so / dt_o
         extra[f"fri_commit_2^{other}_ms"] = 1e3 * dt_o / so
         d_o.free()
+
+        # ---- config 1 widened: full prove (commit + query phase) and host verify at 2^20, on a low-degree codeword ----
+        lp = 20
+        d_pc = resident_codeword(1 << (lp - 2), 4000 + rank)
+        d_pw = ctx.alloc((1 << lp) * 16)
+        _lib.check(_lib.lib.sh_dev_coset_lde(H, d_pc.ptr, lp - 2, 2, _u64p(scalar(sa.GENERATOR)), d_pw.ptr))
+        fri_p = sa.Fri(sa.GENERATOR, None, 1 << lp, 4, 17, ctx=ctx)
+        box_ps = []
+
+        def prove():
+            box_ps[:] = [sa.ProofStream()]
+            fri_p.prove(d_pw, box_ps[0])
+        dt_p = timed(prove, 5, 1)
+        extra[f"fri_prove_2^{lp}_ms"] = 1e3 * dt_p / 5
+        ser = box_ps[0].serialize()
+        t0 = time.perf_counter()
+        okv, _why = fri_p.verify(sa.ProofStream.deserialize(ser))
+        extra[f"fri_verify_host_2^{lp}_ms"] = 1e3 * (time.perf_counter() - t0)
+        extra[f"fri_proof_2^{lp}_bytes"] = len(ser)
+        extra[f"fri_proof_2^{lp}_accepted"] = bool(okv)
+        d_pc.free(); d_pw.free()
     out["extra"] = extra
 
     # ---- N > 1 only: ONE 2^log_n transform / commit spread over all ranks (BASELINE config 5; strong scaling, RCCL
