@@ -8,6 +8,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <new>
 #include <atomic>
@@ -53,8 +54,10 @@ struct sh_ctx {
     bool mail_pending = false;                   // the root of the last reduction arrives through the mailbox
     uint64_t mail_fallbacks = 0;
     std::map<uint32_t, fp*> tw_cache;            // key = log_n*2 + inverse
-    uint8_t* h_batch = nullptr;                  // pinned staging for batched commits: roots (B*64) | c0 (B*16)
+    uint8_t* h_batch = nullptr;                  // pinned, device-mapped staging for batched commits: roots (B*64) | c0 (B*16)
+    uint8_t* d_hbatch = nullptr;                 // device view of h_batch
     size_t h_batch_bytes = 0;
+    uint32_t batch_done_total = 0;               // running total of workgroups that have reported through d_flag[16]
 };
 
 static int32_t ensure_scratch(sh_ctx* c, int slot, size_t bytes, void** out) {
@@ -143,6 +146,7 @@ int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out) {
         c->own_stream = true;
     }
     e = hipMalloc(&c->d_flag, 256);
+    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, 256);
     if (e == hipSuccess) e = hipMalloc(&c->d_root, 256);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_pinned, 256, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_mail, 256, hipHostMallocMapped | hipHostMallocCoherent);
@@ -309,21 +313,26 @@ static int32_t merkle_root_from_elems(sh_ctx* c, const fp* d_elems, size_t L) {
 }
 // Bring the root of the last reduction to the host.  Fast path: the last kernel wrote root + sequence number
 // into pinned host memory; poll for it (no interrupt-driven stream synchronise on the serial FRI chain).
+// poll the mailbox flag for c->mail_seq; *got = false if the stream drained without it (caller takes a copy path)
+static int32_t wait_mailbox(sh_ctx* c, bool* got) {
+    const uint32_t* flag = reinterpret_cast<const uint32_t*>(c->h_mail + 64);
+    uint64_t spins = 0;
+    *got = false;
+    for (;;) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->mail_seq) { *got = true; return SH_OK; }
+        if ((++spins & 0xfff) == 0) {
+            hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) { *got = (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->mail_seq); return SH_OK; }
+            if (e != hipErrorNotReady) return sh_failf(SH_EHIP, "stream failed while waiting for a Merkle root: %s", hipGetErrorString(e));
+        }
+        __builtin_ia32_pause();
+    }
+}
 static int32_t fetch_root(sh_ctx* c, uint8_t root[64]) {
     if (c->mail_pending) {
         c->mail_pending = false;
-        const uint32_t* flag = reinterpret_cast<const uint32_t*>(c->h_mail + 64);
-        uint64_t spins = 0;
         bool got = false;
-        for (;;) {
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->mail_seq) { got = true; break; }
-            if ((++spins & 0xfff) == 0) {
-                hipError_t e = hipStreamQuery(c->stream);
-                if (e == hipSuccess) { got = (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->mail_seq); break; }
-                if (e != hipErrorNotReady) return sh_failf(SH_EHIP, "stream failed while waiting for a Merkle root: %s", hipGetErrorString(e));
-            }
-            __builtin_ia32_pause();
-        }
+        SHCHK(wait_mailbox(c, &got));
         if (got) { memcpy(root, c->h_mail, 64); return SH_OK; }
         ++c->mail_fallbacks;                   // stream drained but the mailbox write is not visible: take the copy path
     }
@@ -407,12 +416,59 @@ static int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_
     return SH_OK;
 }
 
+// Worker threads that live for one batched commit and are handed one slice of the B transcripts per round.  They spin
+// (then yield) between rounds: a round's hand-off must cost well under the ~10 us a thread spawn does.
+class SpinPool {
+  public:
+    explicit SpinPool(unsigned workers) {
+        for (unsigned w = 0; w < workers; ++w) th_.emplace_back([this, w] { run(w); });
+    }
+    ~SpinPool() {
+        stop_.store(true, std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        for (auto& t : th_) t.join();
+    }
+    // f(b0, b1) over [0, n) split into workers + 1 contiguous slices; the caller takes the first
+    template <class F>
+    void parallel(size_t n, F&& f) {
+        const size_t T = th_.size() + 1, chunk = (n + T - 1) / T;
+        std::function<void(size_t, size_t)> fn = f;
+        fn_ = &fn; n_ = n; chunk_ = chunk;
+        pending_.store((int)th_.size(), std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        fn(0, chunk < n ? chunk : n);
+        while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    }
+  private:
+    void run(unsigned w) {
+        uint64_t seen = 0;
+        for (;;) {
+            uint32_t spins = 0;
+            while (gen_.load(std::memory_order_acquire) == seen) { if (++spins > 4000) std::this_thread::yield(); else __builtin_ia32_pause(); }
+            ++seen;
+            if (stop_.load(std::memory_order_relaxed)) return;
+            const size_t b0 = (size_t)(w + 1) * chunk_, b1 = b0 + chunk_;
+            (*fn_)(b0 < n_ ? b0 : n_, b1 < n_ ? b1 : n_);
+            pending_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> pending_{0};
+    std::atomic<bool> stop_{false};
+    const std::function<void(size_t, size_t)>* fn_ = nullptr;
+    size_t n_ = 0, chunk_ = 0;
+};
+
 // ------------------------------------------------------------------ batched FRI commit (lock-step rounds)
 // B independent codewords of equal length, back to back.  Every kernel of a round covers all B codewords, so the
 // serial root -> challenge -> fold chain is paid once per round for the whole batch instead of
 // once per commit: this is what makes small commits (config 4: 1024 x 2^14) throughput-bound.
-static int32_t reduce_digests_batch(sh_ctx* c, const digest64* cur, size_t count, size_t B, digest64* d_roots) {
+// `via_mail`: when set and the last step is a quad reduction, the B roots go straight to the pinned host buffer
+// (c->d_hbatch) and the mailbox sequence number announces them (*via_mail = true); otherwise they land in d_roots.
+static int32_t reduce_digests_batch(sh_ctx* c, const digest64* cur, size_t count, size_t B, digest64* d_roots, bool* via_mail = nullptr) {
     uint32_t lg = ilog2(count);
+    if (via_mail) *via_mail = false;
     if (lg == 0) {
         HIPCHK(hipMemcpyAsync(d_roots, cur, B * sizeof(digest64), hipMemcpyDeviceToDevice, c->stream));
         return SH_OK;
@@ -421,7 +477,12 @@ static int32_t reduce_digests_batch(sh_ctx* c, const digest64* cur, size_t count
     while (lg > 0) {
         const size_t total = B << lg;
         const bool wide = total > ((size_t)1 << QUAD_MAX_LOG_COUNT);
-        const uint32_t step = wide ? (lg < 3 ? lg : 3) : (lg < QUAD_MAX_LOG_CHUNK ? lg : QUAD_MAX_LOG_CHUNK);
+        uint32_t step;
+        if (wide) {                            // lane-per-subtree levels only down to what the quad kernel takes (2^17 digests in all)
+            const uint32_t over = ilog2(total) - QUAD_MAX_LOG_COUNT;
+            step = over < 3 ? over : 3;
+            if (step > lg) step = lg;
+        } else step = lg < QUAD_MAX_LOG_CHUNK ? lg : QUAD_MAX_LOG_CHUNK;
         digest64* out = d_roots;
         if (lg != step) {
             void* b;
@@ -430,7 +491,12 @@ static int32_t reduce_digests_batch(sh_ctx* c, const digest64* cur, size_t count
             out = (digest64*)b;
         }
         if (wide) HIPCHK(launch_node_subtree(cur, out, total >> step, step, c->stream));
-        else HIPCHK(launch_quad_reduce(cur, out, total, step, nullptr, 0, c->stream));
+        else if (lg == step && via_mail && c->d_hbatch) {
+            if (++c->mail_seq == 0) c->mail_seq = 1;
+            c->batch_done_total += (uint32_t)B;
+            HIPCHK(launch_quad_reduce(cur, (digest64*)c->d_hbatch, total, step, c->d_mail, c->mail_seq, c->stream, c->d_flag + 16, c->batch_done_total));
+            *via_mail = true;
+        } else HIPCHK(launch_quad_reduce(cur, out, total, step, nullptr, 0, c->stream));
         cur = out; lg -= step;
     }
     return SH_OK;
@@ -458,14 +524,19 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
         if (R > 2) SHCHK(ensure_scratch(c, SCR_IO_B, B * (N / 4) * sizeof(fp), &bufY));
         SHCHK(ensure_scratch(c, SCR_ROOTS, B * sizeof(digest64), &d_roots));
         SHCHK(ensure_scratch(c, SCR_C0, B * sizeof(fp), &d_c0));
-        const size_t need = B * 64 + B * 16;
+        const size_t L_last = N >> (R - 1);
+        const size_t need = B * 64 + B * 16 + B * L_last * sizeof(fp);     // roots | c0 | last codewords
         if (c->h_batch_bytes < need) {
-            if (c->h_batch) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->h_batch)); c->h_batch = nullptr; c->h_batch_bytes = 0; }
-            HIPCHK(hipHostMalloc((void**)&c->h_batch, need, hipHostMallocDefault));
+            if (c->h_batch) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->h_batch)); c->h_batch = nullptr; c->d_hbatch = nullptr; c->h_batch_bytes = 0; }
+            HIPCHK(hipHostMalloc((void**)&c->h_batch, need, hipHostMallocMapped | hipHostMallocCoherent));
+            HIPCHK(hipHostGetDevicePointer((void**)&c->d_hbatch, c->h_batch, 0));
             c->h_batch_bytes = need;
         }
         uint8_t* h_roots = c->h_batch;
         fp* h_c0 = reinterpret_cast<fp*>(c->h_batch + B * 64);
+        const fp* d_c0_host = reinterpret_cast<const fp*>(c->d_hbatch + B * 64);   // the fold kernel reads c0[b] straight from pinned memory
+        bool via_mail = false;
+        (void)d_c0;
         const fp inv2 = fp_inv(fp_make(2, 0, 0, 0));
         fp off_inv = fp_inv(off);
         auto leaf_k = [&](size_t len) {                 // per-lane subtree depth: fill the chip first, never cross a codeword
@@ -478,15 +549,24 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
             void* dig;
             SHCHK(ensure_scratch(c, SCR_DIG_A, ((B * L) >> K) * sizeof(digest64), &dig));
             HIPCHK(launch_leaf_subtree(cur, (digest64*)dig, (B * L) >> K, K, c->stream));
-            SHCHK(reduce_digests_batch(c, (const digest64*)dig, L >> K, B, (digest64*)d_roots));
+            SHCHK(reduce_digests_batch(c, (const digest64*)dig, L >> K, B, (digest64*)d_roots, &via_mail));
         }
+        unsigned T = std::thread::hardware_concurrency();
+        if (T > 8) T = 8;
+        if (T > B / 16) T = (unsigned)(B / 16);
+        SpinPool pool(T > 1 ? T - 1 : 0);
         const bool dbg = getenv("STARK_HIP_DEBUG") != nullptr;
-        double t_wait = 0, t_host = 0;
+        double t_wait = 0, t_host = 0, t_launch = 0;
         auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         for (uint32_t r = 0; r < R; ++r) {
             const double t0 = now();
-            HIPCHK(hipMemcpyAsync(h_roots, d_roots, B * 64, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
+            bool got = false;
+            if (via_mail) SHCHK(wait_mailbox(c, &got));
+            if (!got) {
+                if (via_mail) ++c->mail_fallbacks;
+                if (!via_mail) HIPCHK(hipMemcpyAsync(h_roots, d_roots, B * 64, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));          // (via_mail: the stream drained, so the roots are already in h_roots)
+            }
             const double t1 = now();
             t_wait += t1 - t0;
             const bool want = r + 1 < R;
@@ -505,34 +585,33 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
                     }
                 }
             };
-            unsigned T = std::thread::hardware_concurrency();
-            if (T > 16) T = 16;
-            if (T > B / 32) T = (unsigned)(B / 32);
-            if (T <= 1) per_codeword(0, B);
-            else {
-                std::vector<std::thread> th;
-                const size_t chunk = (B + T - 1) / T;
-                for (unsigned t = 1; t < T; ++t) th.emplace_back(per_codeword, t * chunk < B ? t * chunk : B, (t + 1) * chunk < B ? (t + 1) * chunk : B);
-                per_codeword(0, chunk < B ? chunk : B);
-                for (auto& x : th) x.join();
-            }
+            pool.parallel(B, per_codeword);
             if (failed) return sh_fail(SH_ECALLBACK, "fri_commit_batch: transcript update failed");
             t_host += now() - t1;
-            if (!want) { if (dbg) fprintf(stderr, "[stark_hip] batch B=%zu N=%zu: wait %.0f us, host transcript %.0f us over %u rounds\n", B, N, t_wait, t_host, R); break; }
-            HIPCHK(hipMemcpyAsync(d_c0, h_c0, B * sizeof(fp), hipMemcpyHostToDevice, c->stream));
+            if (!want) { if (dbg) fprintf(stderr, "[stark_hip] batch B=%zu N=%zu: wait %.0f us, host transcript %.0f us, launches %.0f us over %u rounds\n", B, N, t_wait, t_host, t_launch, R); break; }
+            const double t2 = now();
             const size_t half = L / 2;
             fp* next = (fp*)((r & 1) ? bufY : bufX);
             const uint32_t K = leaf_k(half);
             void* dig;
             SHCHK(ensure_scratch(c, SCR_DIG_A, ((B * half) >> K) * sizeof(digest64), &dig));
-            HIPCHK(launch_fold_leaf_subtree(cur, L, B, (const fp*)d_c0, fp_zero(), tw_inv, log_N, r, next, (digest64*)dig, K, c->stream));
-            SHCHK(reduce_digests_batch(c, (const digest64*)dig, half >> K, B, (digest64*)d_roots));
+            HIPCHK(launch_fold_leaf_subtree(cur, L, B, d_c0_host, fp_zero(), tw_inv, log_N, r, next, (digest64*)dig, K, c->stream));
+            SHCHK(reduce_digests_batch(c, (const digest64*)dig, half >> K, B, (digest64*)d_roots, &via_mail));
             cur = next; L = half;
             off_inv = fp_mul(off_inv, off_inv);
+            t_launch += now() - t2;
         }
     }
-    HIPCHK(hipMemcpyAsync(last_out, cur, B * L * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    const auto t_tail0 = std::chrono::steady_clock::now();
+    if (R > 0 && c->h_batch && c->h_batch_bytes >= B * 80 + B * L * sizeof(fp)) {       // through pinned staging: a pageable D2H is several times slower
+        uint8_t* stage = c->h_batch + B * 80;
+        HIPCHK(hipMemcpyAsync(stage, cur, B * L * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(last_out, stage, B * L * sizeof(fp));
+    } else {
+        HIPCHK(hipMemcpyAsync(last_out, cur, B * L * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     *last_len = L;
     {
         std::atomic<int> failed{0};
@@ -550,6 +629,8 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
         }
         if (failed) return sh_fail(SH_ECALLBACK, "fri_commit_batch: pushing the last codeword failed");
     }
+    if (getenv("STARK_HIP_DEBUG")) fprintf(stderr, "[stark_hip] batch tail (last codewords to host + push): %.0f us\n",
+                                           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_tail0).count());
     return SH_OK;
 }
 

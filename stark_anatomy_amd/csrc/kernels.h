@@ -47,7 +47,8 @@ hipError_t launch_merkle_tail(const digest64* in, digest64* root, size_t n_in, h
 // out[i] = Merkle root of in[i << log_chunk .. +2^log_chunk), 1 <= log_chunk <= 9; four lanes per compression,
 // levels in LDS.  With `mailbox` (single-workgroup launch only) the root + `seq` also go to pinned host memory.
 #define QUAD_MAX_LOG_CHUNK 9
-hipError_t launch_quad_reduce(const digest64* in, digest64* out, size_t n_in, uint32_t log_chunk, uint64_t* mailbox, uint32_t seq, hipStream_t s);
+hipError_t launch_quad_reduce(const digest64* in, digest64* out, size_t n_in, uint32_t log_chunk, uint64_t* mailbox, uint32_t seq, hipStream_t s,
+                              uint32_t* counter = nullptr, uint32_t target = 0);
 
 // ---- hash_kernels.hip (FRI round) ----
 // generic split-and-fold (any omega): out[i] = (a+b)/2 + c0·omega^-i·(a-b),  c0 = alpha/(2·offset)

@@ -65,8 +65,11 @@ __device__ __forceinline__ uint64_t qrotr(uint64_t v) {
 // out[blockIdx] = Merkle root of in[blockIdx << log_chunk .. +2^log_chunk), 1 <= log_chunk <= 9.
 // If `mailbox` is set (single-workgroup launch), the root and then the sequence number are also written to
 // pinned host memory so the host can pick the root up by polling instead of a stream synchronise.
+// Multi-workgroup form of the same hand-off (batched commits: one root per workgroup): `out` is then the device view of
+// pinned host memory, every workgroup stores its root there with system-scope stores, bumps `counter`, and the
+// workgroup that brings it to `target` publishes `seq`.  (`counter` only ever grows; the host passes the running total.)
 __global__ __launch_bounds__(QR_THREADS) void k_quad_reduce(const digest64* __restrict__ in, digest64* __restrict__ out, uint32_t log_chunk,
-                                                            uint64_t* __restrict__ mailbox, uint32_t seq) {
+                                                            uint64_t* __restrict__ mailbox, uint32_t seq, uint32_t* __restrict__ counter, uint32_t target) {
     // Level buffers hold digest PAIRS (= one node's 128-byte message) at a stride of 144 bytes: with the natural 128 the
     // same message word of all 16 quads of a wave falls in one LDS bank (rocprof: SQ_LDS_BANK_CONFLICT = 70 % of
     // LDS-active cycles); 16 bytes of padding rotate consecutive pairs by 4 banks and keep 16-byte alignment.
@@ -121,6 +124,19 @@ __global__ __launch_bounds__(QR_THREADS) void k_quad_reduce(const digest64* __re
         __syncthreads();
         const uint32_t t = s_off; s_off = d_off; d_off = t;
     }
+    if (counter) {
+        if (tid < 8) __hip_atomic_store(&out[blockIdx.x].h[tid], sm[s_off + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
+            if (done == target) {
+                __threadfence_system();
+                __hip_atomic_store(reinterpret_cast<uint32_t*>(mailbox + 8), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
     if (tid < 8) {
         const uint64_t w = sm[s_off + tid];
         out[blockIdx.x].h[tid] = w;
@@ -132,10 +148,12 @@ __global__ __launch_bounds__(QR_THREADS) void k_quad_reduce(const digest64* __re
     }
 }
 
-hipError_t launch_quad_reduce(const digest64* in, digest64* out, size_t n_in, uint32_t log_chunk, uint64_t* mailbox, uint32_t seq, hipStream_t s) {
+hipError_t launch_quad_reduce(const digest64* in, digest64* out, size_t n_in, uint32_t log_chunk, uint64_t* mailbox, uint32_t seq, hipStream_t s,
+                              uint32_t* counter, uint32_t target) {
     if (log_chunk < 1 || log_chunk > 9 || n_in == 0 || (n_in & ((((size_t)1) << log_chunk) - 1))) return hipErrorInvalidValue;
     const size_t blocks = n_in >> log_chunk;
-    if (mailbox && blocks != 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_quad_reduce, dim3((unsigned)blocks), dim3(QR_THREADS), 0, s, in, out, log_chunk, mailbox, seq);
+    if (mailbox && !counter && blocks != 1) return hipErrorInvalidValue;
+    if (counter && !mailbox) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_quad_reduce, dim3((unsigned)blocks), dim3(QR_THREADS), 0, s, in, out, log_chunk, mailbox, seq, counter, target);
     return hipGetLastError();
 }
