@@ -188,11 +188,13 @@ static size_t pass_lds_bytes(uint32_t log_r, uint32_t log_c, bool is_final) {
 }
 
 hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};             // per device: the attribute belongs to the function on the current device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const uint32_t P = plan.num_passes, log_n = plan.log_n;
     uint32_t consumed = 0;
