@@ -384,3 +384,35 @@ def test_sharded_engine_single_rank(ctx):
     for b in range(B):
         r, _, l, ps = co.fri_commit(cws[b], 4, 17, G)
         assert roots[b].tobytes() == b"".join(r) and (last[b] == l).all() and streams[b] == ps.serialize()
+
+
+def test_two_contexts_in_two_threads():
+    """stark_hip.h: distinct contexts are independent — two host threads, each with its own context and stream on the
+    same GPU, commit and transform concurrently; both must match the oracle."""
+    import threading
+    jobs = [(11, 16), (12, 15)]
+    exp = {}
+    for seed, log_n in jobs:
+        cw = co.splitmix_elems(seed, 1 << log_n)
+        r, _, l, ps = co.fri_commit(cw, 4, 17, G)
+        exp[seed] = (cw, r, l, ps.serialize(), co.ntt(cw[: 1 << 12]))
+    errors = []
+
+    def worker(seed, log_n):
+        try:
+            c = sa.Context(0)
+            cw, r, l, ser, ntt_exp = exp[seed]
+            for _ in range(6):
+                ps = sa.ProofStream()
+                roots, last = sa.Fri(G, None, 1 << log_n, 4, 17, ctx=c).commit(cw, ps)
+                assert [h.as_bytes() for h in roots] == r and np.array_equal(last, l) and ps.serialize() == ser
+                assert np.array_equal(sa.ntt(cw[: 1 << 12], ctx=c), ntt_exp)
+            c.close()
+        except Exception as e:  # surfaced in the main thread
+            errors.append(e)
+    th = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
