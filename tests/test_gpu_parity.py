@@ -416,3 +416,30 @@ def test_two_contexts_in_two_threads():
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def test_c5_full_size_2_24_vs_oracle(ctx):
+    """BASELINE config 5's data at full size, directly against the oracle (no sampling): n = 2^22 coefficients (seed 5)
+    -> coset LDE to N = 2^24 -> full FRI commit; codeword, every root, the last codeword and the serialized proof
+    stream must be identical.  The oracle's leaf hashing / Merkle levels / fold run on 16 host threads (same results
+    for any thread count, tests/test_oracle_golden.py); its NTT is single-threaded (~10 s)."""
+    log_n = 22
+    c = co.splitmix_elems(5, 1 << log_n)
+    d_c = ctx.alloc((1 << log_n) * 16).upload(c)
+    N = 4 << log_n
+    d_cw = ctx.alloc(N * 16)
+    sa.dev_coset_lde(ctx, d_c, log_n, 2, G, d_cw)
+    cw = d_cw.download(np.uint64, (N, 2))
+    exp_cw = co.coset_lde(c, 2, G)
+    assert digest(cw) == digest(exp_cw)
+    ps = sa.ProofStream()
+    roots, last = sa.Fri(G, None, N, 4, 17, ctx=ctx).commit(d_cw, ps)
+    co.set_threads(16)
+    try:
+        r, _, l, ops = co.fri_commit(exp_cw, 4, 17, G)
+    finally:
+        co.set_threads(1)
+    assert [h.as_bytes() for h in roots] == r
+    assert np.array_equal(last, l)
+    assert ps.serialize() == ops.serialize()
+    d_c.free(); d_cw.free()
