@@ -172,13 +172,13 @@ def main():
                 traffic = json.load(open(tpath)).get(f"k_leaf_subtree_log{log_n}")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "valu", "kernel": "k_leaf_subtree", "achieved": achieved / 1e12, "peak": VALU_PEAK_OPS / 1e12,
+        out["roofline"] = {"bound": "valu", "kernel": "k_leaf_subtree_staged", "achieved": achieved / 1e12, "peak": VALU_PEAK_OPS / 1e12,
                            "unit": "Tops/s (32-bit integer VALU lane-ops)", "frac": achieved / VALU_PEAK_OPS, "traffic": traffic,
                            "launch_ms": k_ms, "units_per_launch": {"leaves": N, "leaf_compressions": comp_leaf, "node_compressions": comp_node},
                            "ops_per_leaf_compression": OPS_LEAF, "ops_per_node_compression": OPS_NODE,
                            "compressions_per_s": (comp_leaf + comp_node) / (k_ms * 1e-3)}
         hbm_bytes = N * 16 + n_out * 64
-        out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_leaf_subtree", "achieved": hbm_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_BPS / 1e9,
+        out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_leaf_subtree_staged", "achieved": hbm_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_BPS / 1e9,
                                "unit": "GB/s", "frac": hbm_bytes / (k_ms * 1e-3) / HBM_PEAK_BPS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": hbm_bytes}
         d_dig.free()

@@ -12,6 +12,7 @@
 // unrolled node compression (the loops around them are rolled) so the instruction stream stays
 // inside the instruction cache.  Only the last <= 512 nodes are reduced level by level in LDS by
 // a single workgroup (k_merkle_tail).
+#include <stdlib.h>
 #include "kernels.h"
 
 #define SUBTREE_KMAX 4
@@ -175,6 +176,74 @@ __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const 
     store_digest(digests + i, d);
 }
 
+// K = 3 form of the same kernel with HBM access staged through LDS.  In the plain form lane i reads lo[8i+q], hi[8i+q] and
+// writes out[8i+q] one q at a time, 128 bytes apart from its neighbours: every 128-byte line is touched 8 times over the
+// ~100 us a subtree takes, the lines in flight per XCD (~6 MB) overflow its 4 MB L2, and rocprof shows 4x the algorithmic
+// read traffic (2x for writes).  Here each wave first copies its 512 lo and 512 hi elements with fully coalesced loads
+// into LDS (rows of 8 elements padded to 9 so the later per-lane reads spread over the banks), folds out of LDS, parks
+// the results in the lo slots and writes them back coalesced at the end.  18.4 KB of LDS per wave: 8 waves per CU.
+#define STAGE_ROW 9
+#define STAGE_WAVE_ELEMS (64 * STAGE_ROW)
+__global__ __launch_bounds__(256, 2) void k_fold_leaf_subtree_staged(const fp* __restrict__ cw, uint32_t log_half, const fp* __restrict__ c0_arr, fp c0_single,
+                                                                     const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
+                                                                     fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out) {
+    __shared__ fp s_lo[4 * STAGE_WAVE_ELEMS], s_hi[4 * STAGE_WAVE_ELEMS];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // n_out is a multiple of 64: whole waves are in or out
+    if (i >= n_out) return;
+    const size_t half = (size_t)1 << log_half;
+    const size_t wj0 = (i - lane) << 3;                                        // first output of this wave
+    const size_t b = wj0 >> log_half, ww0 = wj0 & (half - 1);
+    const fp c0_mont = c0_arr ? c0_arr[b] : c0_single;
+    const fp* lo = cw + (b << (log_half + 1)) + ww0;
+    const fp* hi = lo + half;
+    fp* my_lo = s_lo + wave * STAGE_WAVE_ELEMS;
+    fp* my_hi = s_hi + wave * STAGE_WAVE_ELEMS;
+#pragma unroll
+    for (uint32_t t = 0; t < 8; ++t) {
+        const uint32_t e = t * 64 + lane;
+        my_lo[e + (e >> 3)] = lo[e];
+        my_hi[e + (e >> 3)] = hi[e];
+    }
+    __syncthreads();
+    const size_t w0 = ww0 + ((size_t)lane << 3);
+    digest64 d = subtree_reduce(3, [&](uint32_t q) {
+        fp t = mont_mul(load_tw(tw_inv, log_n_table, (w0 + q) << tw_shift), c0_mont);
+        fp v = fold_one(my_lo[lane * STAGE_ROW + q], my_hi[lane * STAGE_ROW + q], t);
+        my_lo[lane * STAGE_ROW + q] = v;
+        return b2b_leaf(fp_lo64(v), fp_hi64(v));
+    });
+    store_digest(digests + i, d);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t t = 0; t < 8; ++t) {
+        const uint32_t e = t * 64 + lane;
+        out[wj0 + e] = my_lo[e + (e >> 3)];
+    }
+}
+
+// The same staging for the first round's leaf-only kernel (K = 3): one coalesced 8 KB read per wave instead of 8 strided
+// passes over it (rocprof: 341 MB fetched per 268 MB of codeword in the plain form).
+__global__ __launch_bounds__(256, SUBTREE_WAVES) void k_leaf_subtree_staged(const fp* __restrict__ elems, digest64* __restrict__ out, size_t n_out) {
+    __shared__ fp s_el[4 * STAGE_WAVE_ELEMS];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const fp* base = elems + ((i - lane) << 3);
+    fp* mine = s_el + wave * STAGE_WAVE_ELEMS;
+#pragma unroll
+    for (uint32_t t = 0; t < 8; ++t) {
+        const uint32_t e = t * 64 + lane;
+        mine[e + (e >> 3)] = base[e];
+    }
+    __syncthreads();
+    digest64 d = subtree_reduce(3, [&](uint32_t q) {
+        fp e = mine[lane * STAGE_ROW + q];
+        return b2b_leaf(fp_lo64(e), fp_hi64(e));
+    });
+    store_digest(out + i, d);
+}
+
 // ---------------------------------------------------------------------------------------------
 static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
@@ -188,6 +257,11 @@ hipError_t launch_hash_leaves(const fp* elems, digest64* out, size_t L, hipStrea
 hipError_t launch_leaf_subtree(const fp* elems, digest64* out, size_t n_out, uint32_t K, hipStream_t s) {
     if (!n_out) return hipSuccess;
     if (K > SUBTREE_KMAX) return hipErrorInvalidValue;
+    static const bool no_stage = getenv("STARK_NO_STAGE") != nullptr;
+    if (K == 3 && (n_out & 255) == 0 && !no_stage) {
+        hipLaunchKernelGGL(k_leaf_subtree_staged, dim3((unsigned)(n_out >> 8)), dim3(256), 0, s, elems, out, n_out);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_leaf_subtree, dim3(grid_for(n_out, 256)), dim3(256), 0, s, elems, out, n_out, K);
     return hipGetLastError();
 }
@@ -215,6 +289,12 @@ hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* 
     uint32_t log_half = 0;
     while (((size_t)1 << log_half) < half) ++log_half;
     const size_t n_out = (B * half) >> K;
+    static const bool no_stage = getenv("STARK_NO_STAGE") != nullptr;
+    if (K == 3 && (n_out & 255) == 0 && log_half >= 9 && !no_stage) {          // whole 256-lane workgroups, waves inside one codeword
+        hipLaunchKernelGGL(k_fold_leaf_subtree_staged, dim3((unsigned)(n_out >> 8)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
+                           log_n_table, tw_shift, out, digests, n_out);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_fold_leaf_subtree, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
                        log_n_table, tw_shift, out, digests, n_out, K);
     return hipGetLastError();
