@@ -1,0 +1,91 @@
+// api_internal.h — shared by the api_*.hip translation units (the host drivers behind include/stark_hip.h): the context,
+// error macros, small host helpers and the internal entry points one unit borrows from another.  Internal.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <functional>
+#include <map>
+#include <new>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/stark_hip.h"
+#include "host_internal.h"
+#include "kernels.h"
+
+
+#define HIPCHK(expr)                                                                                           \
+    do {                                                                                                       \
+        hipError_t _e = (expr);                                                                                \
+        if (_e != hipSuccess) return sh_failf(SH_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define SHCHK(expr) do { int32_t _rc = (expr); if (_rc != SH_OK) return _rc; } while (0)
+
+#define CTXCHK(c)                                                          \
+    do {                                                                   \
+        if (!(c)) return sh_fail(SH_EINVAL, "null sh_ctx");                \
+        HIPCHK(hipSetDevice((c)->device));                                 \
+    } while (0)
+
+// ------------------------------------------------------------------ context
+#define NUM_SCRATCH 12
+enum { SCR_IO_A = 0, SCR_IO_B = 1, SCR_IO_C = 2, SCR_WORK = 3, SCR_DIG_A = 4, SCR_DIG_B = 5, SCR_ROOTS = 6, SCR_C0 = 7,
+       SCR_ARENA = 8, SCR_LEVELS = 9, SCR_IDX = 10, SCR_PATHS = 11 };
+struct sh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void* scratch[NUM_SCRATCH] = {};
+    size_t scratch_bytes[NUM_SCRATCH] = {};
+    uint32_t* d_flag = nullptr;
+    digest64* d_root = nullptr;
+    uint8_t* h_pinned = nullptr;                 // 256 B of pinned host memory (staging for small D2H copies)
+    uint8_t* h_mail = nullptr;                   // pinned, device-mapped mailbox: root[64] | seq (u32)
+    uint64_t* d_mail = nullptr;                  // device view of h_mail
+    uint32_t mail_seq = 0;                       // last sequence number handed to a kernel
+    bool mail_pending = false;                   // the root of the last reduction arrives through the mailbox
+    uint64_t mail_fallbacks = 0;
+    std::map<uint32_t, fp*> tw_cache;            // key = log_n*2 + inverse
+    uint8_t* h_batch = nullptr;                  // pinned, device-mapped staging for batched commits: roots (B*64) | c0 (B*16)
+    uint8_t* d_hbatch = nullptr;                 // device view of h_batch
+    size_t h_batch_bytes = 0;
+    uint32_t batch_done_total = 0;               // running total of workgroups that have reported through d_flag[16]
+};
+
+static inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+static inline uint32_t ilog2(size_t x) { uint32_t l = 0; while (((size_t)1 << l) < x) ++l; return l; }
+static inline fp fp_load_host(const uint64_t v[2]) { return fp_from_u64x2(v[0], v[1]); }
+static inline void fp_store_host(uint64_t v[2], fp a) { v[0] = fp_lo64(a); v[1] = fp_hi64(a); }
+static inline bool fp_is_canonical(fp a) { return fp_to_u128(a) < fp_prime_u128(); }
+
+// G1: g = 85408008396924667383611388730472331217 = 0x4040fbed12ee470f_b5038f9c18f6f7d1, order 2^119
+static inline fp host_generator() { return fp_from_u64x2(0xb5038f9c18f6f7d1ULL, 0x4040fbed12ee470fULL); }
+static inline fp host_root_of_unity(uint32_t log_n) {
+    fp w = fp_to_mont(host_generator());
+    for (uint32_t i = log_n; i < 119; ++i) w = mont_mul(w, w);
+    return fp_from_mont(w);
+}
+
+#define QUAD_MAX_LOG_COUNT 17                  // from this many digests down a tree is reduced four-lanes-per-compression
+
+// api.hip
+int32_t ensure_scratch(sh_ctx* c, int slot, size_t bytes, void** out);
+int32_t get_twiddles(sh_ctx* c, uint32_t log_n, bool inverse, const fp** out);
+// api_merkle.hip
+int32_t reduce_digests(sh_ctx* c, const digest64* cur, size_t count);
+uint32_t leaf_subtree_k(uint32_t log_L);
+int32_t merkle_root_from_elems(sh_ctx* c, const fp* d_elems, size_t L);
+int32_t wait_mailbox(sh_ctx* c, bool* got);
+int32_t fetch_root(sh_ctx* c, uint8_t root[64]);
+// api_fri.hip
+int32_t check_params(const sh_fri_params* p, fp* offset);
+int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_params* prm, sh_transcript_cb cb, void* user,
+                       uint8_t* roots_out, uint64_t* last_out, size_t* last_len, std::vector<const fp*>* keep = nullptr);
+struct PsCbState { sh_proofstream* ps; };
+int32_t ps_callback(void* user, uint32_t round, const uint8_t root[64], int32_t want_alpha, uint64_t alpha_out[2]);
