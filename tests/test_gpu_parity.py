@@ -351,9 +351,11 @@ def test_fri_commit_2_24_properties(ctx):
 
 
 # ------------------------------------------------------------------ batched commits (BASELINE config 4)
-@pytest.mark.parametrize("B,log_n", [(1, 10), (3, 7), (8, 14), (128, 14), (5, 1), (2, 18)])
+@pytest.mark.parametrize("B,log_n", [(1, 10), (3, 7), (8, 14), (128, 14), (5, 1), (2, 18), (8, 19), (4, 22)])
 def test_fri_commit_batch_vs_oracle(ctx, B, log_n):
-    """B lock-step commits == B separate oracle commits: roots, last codewords and every proof stream's bytes."""
+    """B lock-step commits == B separate oracle commits: roots, last codewords and every proof stream's bytes.
+    (8, 19) and (4, 22) reach the LDS-staged K = 3 kernels with per-codeword fold constants."""
+    co.set_threads(16)
     N = 1 << log_n
     cws = np.stack([co.splitmix_elems(1000 + b, N) for b in range(B)])
     t = 17 if log_n > 1 else 0
@@ -373,6 +375,7 @@ def test_fri_commit_batch_vs_oracle(ctx, B, log_n):
     roots2, last2 = fri.commit_batch(d, streams2)
     assert (last2 == last).all() and all(a.serialize() == b_.serialize() for a, b_ in zip(streams, streams2))
     d.free()
+    co.set_threads(1)
 
 
 def test_sharded_engine_single_rank(ctx):
