@@ -22,8 +22,9 @@ elements each), so cw[i] and cw[L/2+i] are on the same card: it hashes both into
 sub-roots are all-gathered (128 B per rank) and reduced to the round's root on every rank, every rank keeps an
 identical transcript replica and derives the same alpha, and the fold of the rank's h outputs is local.  The h
 outputs are slice g of the next codeword; before the next round a point-to-point regroup moves its two halves to
-ranks 2g mod P and (2g+1) mod P.  When slices get small the codeword is all-gathered and every rank finishes the
-remaining rounds locally (the round count depends on the current length only).
+ranks 2g mod P and (2g+1) mod P.  When half-slices drop under `min_half` elements (default 2^16: from there a round is
+latency, not work, and one GPU walks the remaining rounds in under a millisecond) the codeword is all-gathered and every
+rank finishes the remaining rounds locally (the round count depends on the current length only).
 
 `engine` is the local compute.  `GpuEngine` is the product engine (HIP kernels through the C ABI, no fallback);
 tests inject a CPU engine with the same methods to rehearse the exchange logic on gloo ranks.
@@ -335,7 +336,7 @@ def _mul_mod(a, b):
 
 
 def dist_fri_commit(local, N, engine, offset, expansion_factor=4, num_colinearity_tests=17, group=None,
-                    proof_stream=None, min_half=1 << 10):
+                    proof_stream=None, min_half=1 << 16):
     """FRI commit of ONE codeword of N elements spread in natural order over the ranks.
     Every rank returns (roots [R × 64 B], last_codeword (L,2) uint64, proof_stream) — identical on all ranks."""
     P, g = _world_rank(group)
