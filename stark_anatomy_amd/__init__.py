@@ -12,10 +12,11 @@ There is no CPU fallback: importing this package without the built library raise
 """
 from . import _lib  # noqa: F401  (fails loudly if the HIP extension is missing)
 from . import dist  # noqa: F401  (sharding helpers; imports torch lazily)
+from . import dist_ntt  # noqa: F401  (one transform / one commit over several GPUs; imports torch lazily)
 from ._lib import StarkHipError
 from .context import Context, DeviceBuffer, array_to_ints, default_context, elems_to_array
 from .field import GENERATOR, ONE, PRIME, ZERO, FieldElement, FieldVector, generator, root_of_unity
-from .fri import Fri, fold, sample
+from .fri import Fri, fold, sample, sample_indices
 from .merkle import MerkleHash, MerkleTree, commit_elems, hash_leaves
 from .ntt import coset_lde, dev_coset_lde, dev_ntt, intt, ntt
 from .proof_stream import OutOfBoundsReadIndexError, ProofItem, ProofStream, ProofStreamError, SerializationError
