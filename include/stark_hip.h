@@ -114,6 +114,14 @@ int32_t sh_dev_merkle_commit_elems(sh_ctx* ctx, const uint64_t* d_elems, size_t 
  * bottom K+1 levels of merkle.rs:48-60 for n_out independent subtrees in one launch (one subtree per lane).
  * This is the dominant kernel of the commit; also the building block for batches of small commits. */
 int32_t sh_dev_merkle_subtrees(sh_ctx* ctx, const uint64_t* d_elems, size_t n_out, uint32_t K, uint8_t* d_out);
+/* Allocation-free variant of sh_dev_merkle_commit_elems.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot allocate device memory — code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * Same kernels and the same root as sh_dev_merkle_commit_elems, but the digest buffers live in a fixed 8 MiB + 33 KiB
+ * __device__ array of the library (one copy per GPU, held until the process ends) instead of the context's growable
+ * scratch; it calls no hipMalloc / hipFree.  L must be a power of two <= 2^SH_NOALLOC_MAX_LOG_L (else SH_EINVAL).
+ * Calls on the same GPU share that array: calls that overlap on one GPU (two contexts / streams) race. */
+#define SH_NOALLOC_MAX_LOG_L 20
+int32_t sh_dev_merkle_commit_elems_noalloc(sh_ctx* ctx, const uint64_t* d_elems, size_t L, uint8_t root[64]);
 /* `MerkleTree::open(index)`, merkle.rs:70-108: path[0] = sibling leaf … path[log2 L − 1] = sibling
  * of the root's child; *path_len = log2 L.  SH_EBOUNDS if index >= L or L < 2 (merkle.rs:75,104). */
 int32_t sh_merkle_open(sh_ctx* ctx, const uint8_t* leaves, size_t L, size_t index, uint8_t* path, size_t* path_len);

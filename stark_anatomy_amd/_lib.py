@@ -83,6 +83,7 @@ _PROTOS = {
     "sh_dev_hash_leaves": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sh_merkle_commit_elems": (C.c_int32, [ctx_t, u64p, C.c_size_t, u8p]),
     "sh_dev_merkle_commit_elems": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, u8p]),
+    "sh_dev_merkle_commit_elems_noalloc": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, u8p]),
     "sh_dev_merkle_subtrees": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "sh_merkle_open": (C.c_int32, [ctx_t, u8p, C.c_size_t, C.c_size_t, u8p, szp]),
     "sh_fri_fold": (C.c_int32, [ctx_t, u64p, C.c_size_t, u64p, u64p, u64p, u64p]),

@@ -74,6 +74,7 @@ int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return sh_failf(SH_EHIP, "sh_ctx_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    SHCHK(noalloc_init_device(device));            // resolves the fixed __device__ scratch of the no-alloc entry point on this GPU
     sh_ctx* c = new (std::nothrow) sh_ctx();
     if (!c) return sh_fail(SH_ENOMEM, "sh_ctx_create: out of memory");
     c->device = device;

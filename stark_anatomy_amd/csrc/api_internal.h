@@ -83,6 +83,8 @@ uint32_t leaf_subtree_k(uint32_t log_L);
 int32_t merkle_root_from_elems(sh_ctx* c, const fp* d_elems, size_t L);
 int32_t wait_mailbox(sh_ctx* c, bool* got);
 int32_t fetch_root(sh_ctx* c, uint8_t root[64]);
+// api_noalloc.hip
+int32_t noalloc_init_device(int device);
 // api_fri.hip
 int32_t check_params(const sh_fri_params* p, fp* offset);
 int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_params* prm, sh_transcript_cb cb, void* user,
