@@ -128,7 +128,9 @@ int32_t sh_merkle_open(sh_ctx* ctx, const uint8_t* leaves, size_t L, size_t inde
 
 /* ---------------- FRI split-and-fold ----------------
  * out[i] = 2^-1·((1 + alpha/(offset·omega^i))·cw[i] + (1 − alpha/(offset·omega^i))·cw[L/2+i]),
- * i in [0, L/2); omega must be the primitive L-th root w_L (checked). */
+ * i in [0, L/2).  The formula is evaluated as written for ANY non-zero canonical omega (not checked against w_L: a FRI round
+ * passes the primitive L-th root w_L, the multi-GPU path passes the same root with a slice offset); SH_EDIVZERO if offset or
+ * omega is zero (field.rs:101-103), SH_EINVAL if a scalar is not canonical. */
 int32_t sh_fri_fold(sh_ctx* ctx, const uint64_t* cw, size_t L, const uint64_t alpha[2],
                     const uint64_t offset[2], const uint64_t omega[2], uint64_t* out);
 int32_t sh_dev_fri_fold(sh_ctx* ctx, const uint64_t* d_cw, size_t L, const uint64_t alpha[2],
@@ -198,7 +200,8 @@ int32_t sh_dev_fri_commit_proofstream(sh_ctx* ctx, const uint64_t* d_codeword, s
  * sh_merkle_open.  The _elems form hashes field elements to leaves first (G2). */
 int32_t sh_merkle_open_batch(sh_ctx* ctx, const uint8_t* leaves, size_t L, const uint64_t* indices, size_t n_idx, uint8_t* paths);
 int32_t sh_dev_merkle_open_elems_batch(sh_ctx* ctx, const uint64_t* d_elems, size_t L, const uint64_t* indices, size_t n_idx, uint8_t* paths);
-/* G10: `number` indices in [0,size) with pairwise distinct residues mod reduced_size, from Blake2b512(seed || counter_le64). Host only. */
+/* G10: `number` indices in [0,size) with pairwise distinct residues mod reduced_size, from Blake2b512(seed || counter_le64). Host only.
+ * SH_EINVAL if number > min(size, reduced_size): that many distinct residues do not exist. */
 int32_t sh_fri_sample_indices(const uint8_t seed[32], uint64_t size, uint64_t reduced_size, uint32_t number, uint64_t* out);
 /* G11: commit (as sh_fri_commit_proofstream) followed by the query phase.  Items pushed after the last codeword, per
  * round r < R-1: t x {"Leaves":[cw_r[a],cw_r[b],cw_(r+1)[a]]}, then per test the paths of a, b = a + L_r/2 (tree r) and
@@ -212,6 +215,10 @@ int32_t sh_dev_fri_prove(sh_ctx* ctx, const uint64_t* d_codeword, size_t N, cons
  * sh_last_error() names the failed check.  Returns SH_OK unless the arguments themselves are invalid. */
 int32_t sh_fri_verify(sh_proofstream* stream, size_t N, const sh_fri_params* params, int32_t* accepted,
                       uint64_t* top_level_indices, size_t* n_indices);
+/* Name and version of the item / sampling formats above (G2, G3, G6, G9-G12), e.g. "stark-anat-fri/1".  The reference crate
+ * pins none of them (it has no FRI layer) and they are NOT interoperable with the upstream Python tutorial (which hashes
+ * decimal strings, appends bytes(counter) and pickles its stream); a later pin by the reference bumps the version. */
+const char* sh_fri_proof_format(void);
 
 /* Batch of B independent commits of equal length N (BASELINE config 4: 1024 x 2^14), codewords back to back
  * (B*N elements).  Rounds run in lock step: every kernel covers all B codewords, each codeword has its own

@@ -115,6 +115,7 @@ _PROTOS = {
     "sh_fri_sample_indices": (C.c_int32, [u8p, C.c_uint64, C.c_uint64, C.c_uint32, u64p]),
     "sh_fri_prove": (C.c_int32, [ctx_t, u64p, C.c_size_t, C.POINTER(FriParams), ps_t, u64p, szp]),
     "sh_dev_fri_prove": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.POINTER(FriParams), ps_t, u64p, szp]),
+    "sh_fri_proof_format": (C.c_char_p, []),
     "sh_fri_verify": (C.c_int32, [ps_t, C.c_size_t, C.POINTER(FriParams), C.POINTER(C.c_int32), u64p, szp]),
     "sh_sha256": (C.c_int32, [C.c_char_p, C.c_size_t, u8p]),
     "sh_blake2b512": (C.c_int32, [C.c_char_p, C.c_size_t, u8p]),

@@ -106,6 +106,7 @@ int32_t sh_ctx_destroy(sh_ctx* c) {
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
     if (c->h_batch) (void)hipHostFree(c->h_batch);
+    if (c->h_chain) (void)hipHostFree(c->h_chain);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SH_OK;

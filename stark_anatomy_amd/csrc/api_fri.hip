@@ -10,70 +10,270 @@ int32_t check_params(const sh_fri_params* p, fp* offset) {
     if (!fp_is_canonical(*offset) || fp_is_zero(*offset)) return sh_fail(SH_EINVAL, "fri: offset must be a non-zero canonical field element");
     return SH_OK;
 }
-// `keep`: when set, every round's codeword stays resident (round r >= 1 at offset N - N/2^(r-1) of one N-element arena,
-// instead of the two ping-pong buffers)  and its device pointer is recorded — the query phase opens them afterwards.
-int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_params* prm, sh_transcript_cb cb, void* user,
-                              uint8_t* roots_out, uint64_t* last_out, size_t* last_len, std::vector<const fp*>* keep) {
-    CTXCHK(c);
-    if (!d_cw || !cb || !roots_out || !last_out || !last_len) return sh_fail(SH_EINVAL, "fri_commit: null pointer");
-    if (!is_pow2(N)) return sh_fail(SH_EINVAL, "fri_commit: N must be a power of two");
+// ------------------------------------------------------------------ the commit chain
+// One pinned, device-mapped buffer per context carries the serial chain of a commit between GPU and host:
+//   header (64 B: word 0 = abort status written by a wait kernel that timed out)
+//   R root records  : B roots (64 B each) | 64-byte line whose first word is the sequence number
+//   R c0 records    : B fold constants (16 B each, Montgomery form), padded to 64 | sequence line
+//   staging for the B last codewords
+// A sequence word equal to the commit's generation number means "published"; bit 31 on a c0 record means "abort".
+struct ChainLayout {
+    size_t B, R, rec_root, rec_c0, off_root, off_c0, off_last, total;
+    ChainLayout(size_t B_, size_t R_, size_t last_bytes) : B(B_), R(R_) {
+        rec_root = B * 64 + 64;
+        rec_c0 = ((B * 16 + 63) & ~(size_t)63) + 64;
+        off_root = 64;
+        off_c0 = off_root + R * rec_root;
+        off_last = off_c0 + R * rec_c0;
+        total = off_last + last_bytes;
+    }
+    size_t roots(size_t r) const { return off_root + r * rec_root; }
+    size_t root_seq(size_t r) const { return roots(r) + B * 64; }
+    size_t c0(size_t r) const { return off_c0 + r * rec_c0; }
+    size_t c0_seq(size_t r) const { return c0(r) + rec_c0 - 64; }
+};
+static int32_t ensure_chain(sh_ctx* c, size_t bytes) {
+    if (c->chain_bytes >= bytes) return SH_OK;
+    if (c->h_chain) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->h_chain)); c->h_chain = nullptr; c->d_chain = nullptr; c->chain_bytes = 0; }
+    const size_t want = (bytes + 4095) & ~(size_t)4095;
+    HIPCHK(hipHostMalloc((void**)&c->h_chain, want, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_chain, 0, want);
+    HIPCHK(hipHostGetDevicePointer((void**)&c->d_chain, c->h_chain, 0));
+    c->chain_bytes = want;
+    return SH_OK;
+}
+// Releases the GPU on every exit path once kernels that wait for the host are in flight: publishes "abort" in every c0
+// record not yet published and drains the stream.
+struct ChainGuard {
+    sh_ctx* c; const ChainLayout* lay; uint32_t gen; size_t next_c0 = 0, waits = 0; bool armed = false;   // waits: c0 records 0..waits-1 have a kernel waiting
+    ~ChainGuard() {
+        if (!armed) return;
+        for (size_t r = next_c0; r < waits; ++r)
+            __atomic_store_n(reinterpret_cast<uint32_t*>(c->h_chain + lay->c0_seq(r)), gen | 0x80000000u, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(c->stream);
+    }
+};
+static int32_t wait_seq(sh_ctx* c, const uint32_t* flag, uint32_t gen) {
+    uint64_t spins = 0;
+    for (;;) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == gen) return SH_OK;
+        if ((++spins & 0x3fff) == 0) {
+            hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == gen) return SH_OK;
+                return sh_fail(SH_EHIP, "fri_commit: the stream drained without publishing a Merkle root (a round timed out waiting for its challenge?)");
+            }
+            if (e != hipErrorNotReady) return sh_failf(SH_EHIP, "stream failed while waiting for a Merkle root: %s", hipGetErrorString(e));
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+// Forest reduction: B trees of 2^lg digests each, back to back at `cur` -> B roots in the round's record + sequence word.
+// Wide levels: one 2^K-node subtree per lane; from 2^17 digests down: four lanes per compression, levels in LDS.
+static int32_t enqueue_forest_reduce(sh_ctx* c, const digest64* cur, digest64* other, digest64* self, uint32_t lg, size_t B, uint8_t* d_rec, uint32_t gen) {
+    uint64_t* rec_roots = reinterpret_cast<uint64_t*>(d_rec);
+    uint32_t* rec_seq = reinterpret_cast<uint32_t*>(d_rec + B * 64);
+    if (lg == 0) { HIPCHK(launch_publish_digests(cur, B, rec_roots, rec_seq, gen, c->stream)); return SH_OK; }
+    while (lg > 0) {
+        const size_t total = B << lg;
+        digest64* out = other;
+        uint32_t step;
+        if (total > ((size_t)1 << QUAD_MAX_LOG_COUNT)) {
+            const uint32_t over = ilog2(total) - QUAD_MAX_LOG_COUNT;
+            step = over < 3 ? over : 3;
+            if (step > lg) step = lg;
+            if (step == lg) {                                      // B > 2^17 trees: finish them lane-per-subtree, then publish
+                HIPCHK(launch_node_subtree(cur, out, total >> step, step, c->stream));
+                HIPCHK(launch_publish_digests(out, B, rec_roots, rec_seq, gen, c->stream));
+                return SH_OK;
+            }
+            HIPCHK(launch_node_subtree(cur, out, total >> step, step, c->stream));
+        } else {
+            step = lg <= QUAD_MAX_LOG_CHUNK ? lg : (total >= ((size_t)1 << 14) ? QUAD_MAX_LOG_CHUNK : (lg + 1) / 2);   // full workgroups while there is work; balanced launches once it is latency only
+            if (step == lg) {
+                if (B == 1) HIPCHK(launch_quad_reduce(cur, c->d_root, total, step, rec_roots, gen, c->stream));
+                else {
+                    c->batch_done_total += (uint32_t)B;
+                    HIPCHK(launch_quad_reduce(cur, reinterpret_cast<digest64*>(d_rec), total, step, reinterpret_cast<uint64_t*>(d_rec + B * 64 - 64), gen, c->stream,
+                                              c->d_flag + 16, c->batch_done_total));
+                }
+                return SH_OK;
+            }
+            HIPCHK(launch_quad_reduce(cur, out, total, step, nullptr, 0, c->stream));
+        }
+        cur = out; other = self; self = out; lg -= step;
+    }
+    return SH_OK;
+}
+
+// Per round the host side gets the B roots and, when `want`, returns the B challenges (canonical).
+typedef std::function<int32_t(uint32_t r, const uint8_t* roots, bool want, fp* alpha_out)> RoundFn;
+
+// The commit of B equal-length codewords stored back to back, rounds in lock step (B = 1: one codeword).
+// `keep`: when set (B == 1), every round's codeword stays resident (round r >= 1 at offset N - N/2^(r-1) of one N-element
+// arena, instead of the two ping-pong buffers) and its device pointer is recorded — the query phase opens them afterwards.
+static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, const sh_fri_params* prm, const RoundFn& fn,
+                               uint64_t* last_out, size_t* last_len, std::vector<const fp*>* keep) {
     const uint32_t log_N = ilog2(N);
-    if (log_N > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "fri_commit: N > 2^%d", SH_MAX_LOG_N);
     fp off;
     SHCHK(check_params(prm, &off));
     const uint32_t R = sh_fri_num_rounds(N, prm->expansion, prm->num_colinearity_tests);
-    const fp* cur = d_cw;
+    if (keep) { keep->clear(); keep->push_back(d_cws); }
+    if (R == 0) {
+        HIPCHK(hipMemcpyAsync(last_out, d_cws, B * N * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *last_len = N;
+        return SH_OK;
+    }
+    // ---- everything that allocates or synchronises happens before the first kernel is enqueued
+    const size_t L_last = N >> (R - 1);
+    const size_t last_bytes = B * L_last * sizeof(fp);
+    const bool stage_last = last_bytes <= ((size_t)64 << 20);
+    const ChainLayout lay(B, R, stage_last ? last_bytes : 0);
+    SHCHK(ensure_chain(c, lay.total));
+    const fp* tw_inv;
+    SHCHK(get_twiddles(c, log_N, true, &tw_inv));
+    void *bufX = nullptr, *bufY = nullptr, *arena = nullptr, *digA, *digB, *d_c0;
+    if (keep) { if (R > 1) SHCHK(ensure_scratch(c, SCR_ARENA, N * sizeof(fp), &arena)); }
+    else {
+        if (R > 1) SHCHK(ensure_scratch(c, SCR_IO_A, B * (N / 2) * sizeof(fp), &bufX));
+        if (R > 2) SHCHK(ensure_scratch(c, SCR_IO_B, B * (N / 4) * sizeof(fp), &bufY));
+    }
+    auto leaf_k = [&](size_t len) {                 // per-lane subtree depth: fill the chip first, never cross a codeword
+        uint32_t K = leaf_subtree_k(ilog2(B * len));
+        const uint32_t lg = ilog2(len);
+        return K < lg ? K : lg;
+    };
+    const size_t dig0 = (B * N) >> leaf_k(N);
+    SHCHK(ensure_scratch(c, SCR_DIG_A, dig0 * sizeof(digest64), &digA));
+    SHCHK(ensure_scratch(c, SCR_DIG_B, (dig0 / 2 ? dig0 / 2 : 1) * sizeof(digest64), &digB));
+    SHCHK(ensure_scratch(c, SCR_C0, B * sizeof(fp), &d_c0));
+    uint32_t gen = (c->chain_gen + 1) & 0x7fffffffu;
+    if (gen == 0) gen = 1;
+    c->chain_gen = gen;
+    static const double timeout_s = [] { const char* e = getenv("STARK_HIP_CHAIN_TIMEOUT_S"); double v = e ? atof(e) : 0; return v > 0 ? v : 20.0; }();
+    const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1e8);
+    uint32_t* d_abort = c->d_flag + 32;
+    uint32_t* h_abort = reinterpret_cast<uint32_t*>(c->h_chain);
+    uint32_t* hd_abort = reinterpret_cast<uint32_t*>(c->d_chain);
+    *h_abort = 0;
+    HIPCHK(hipMemsetAsync(d_abort, 0, 4, c->stream));
+
+    // ---- enqueue rounds one ahead of the chain: round r+1's kernels (which start by waiting for challenge r) are on the
+    // stream before root r is picked up, and round r+2 is enqueued while the GPU works on round r+1.
+    ChainGuard guard{c, &lay, gen};
+    guard.armed = true;
+    const fp* cur = d_cws;
     size_t L = N;
-    if (R > 0) {
-        const fp* tw_inv;
-        SHCHK(get_twiddles(c, log_N, true, &tw_inv));
-        void *bufX = nullptr, *bufY = nullptr, *arena = nullptr;
-        if (keep) { keep->clear(); keep->push_back(d_cw); if (R > 1) SHCHK(ensure_scratch(c, SCR_ARENA, N * sizeof(fp), &arena)); }
-        else {
-            if (R > 1) SHCHK(ensure_scratch(c, SCR_IO_A, (N / 2) * sizeof(fp), &bufX));
-            if (R > 2) SHCHK(ensure_scratch(c, SCR_IO_B, (N / 4) * sizeof(fp), &bufY));
-        }
-        const fp inv2 = fp_inv(fp_make(2, 0, 0, 0));
-        fp off_inv = fp_inv(off);                  // (off^(2^r))^-1 = (off^-1)^(2^r): one inversion for the whole commit
-        uint8_t root[64];
-        SHCHK(merkle_root_from_elems(c, cur, L));
-        SHCHK(fetch_root(c, root));
-        const bool dbg = getenv("STARK_HIP_DEBUG") != nullptr;     // per-round host timing: callback / enqueue / wait for the root
-        auto now = [] { return std::chrono::steady_clock::now(); };
-        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        for (uint32_t r = 0; r < R; ++r) {
-            memcpy(roots_out + 64 * (size_t)r, root, 64);
-            const int32_t want = (r + 1 < R) ? 1 : 0;
-            uint64_t alpha_w[2] = {0, 0};
-            const auto t0 = now();
-            if (cb(user, r, root, want, alpha_w) != 0) return sh_failf(SH_ECALLBACK, "fri_commit: transcript callback failed in round %u", r);
-            if (!want) break;
-            const fp alpha = fp_load_host(alpha_w);
-            if (!fp_is_canonical(alpha)) return sh_fail(SH_EINVAL, "fri_commit: callback returned a non-canonical alpha");
-            // c0 = alpha · 2^-1 · offset^-1, kept in Montgomery form for the kernel
-            const fp c0 = fp_mul(fp_mul(alpha, inv2), off_inv);
+    uint32_t enq = 0;                              // rounds enqueued so far
+    static const bool use_round_wg = getenv("STARK_NO_ROUND_WG") == nullptr;
+    auto enqueue_round = [&]() -> int32_t {
+        const uint32_t r = enq;
+        uint8_t* rec = c->d_chain + lay.roots(r);
+        // small rounds: the whole round (wait, fold, leaf hash, bottom 7 levels) is one launch, plus one for the levels above
+        auto small_round = [&](bool fold, const fp* in, fp* out, uint32_t lg_tree) -> int32_t {
+            const size_t blocks = ((B << lg_tree) + 127) / 128;
+            uint32_t target = 0;
+            if (lg_tree <= 7 && blocks > 1) { c->batch_done_total += (uint32_t)blocks; target = c->batch_done_total; }
+            const bool poll_inside = fold && B == 1 && blocks <= 32;       // else a wait kernel first: few lanes may touch host memory
+            if (fold && !poll_inside)
+                HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)),
+                                      (fp*)d_c0, B, d_abort, hd_abort, timeout_ticks, c->stream));
+            HIPCHK(launch_round_wg(fold, in, out, lg_tree, B, poll_inside ? reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)) : nullptr, gen,
+                                   poll_inside ? reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)) : nullptr, (const fp*)d_c0, d_abort, hd_abort, timeout_ticks, tw_inv, log_N,
+                                   fold ? r - 1 : 0, (digest64*)digA, reinterpret_cast<uint64_t*>(rec), reinterpret_cast<uint32_t*>(rec + B * 64), c->d_flag + 16, target,
+                                   c->stream));
+            if (lg_tree > 7) SHCHK(enqueue_forest_reduce(c, (const digest64*)digA, (digest64*)digB, (digest64*)digA, lg_tree - 7, B, rec, gen));
+            return SH_OK;
+        };
+        if (r == 0) {
+            if (use_round_wg && (B << log_N) <= ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL) && log_N >= 1) SHCHK(small_round(false, cur, nullptr, log_N));
+            else {
+                const uint32_t K = leaf_k(L);
+                HIPCHK(launch_leaf_subtree(cur, (digest64*)digA, (B * L) >> K, K, c->stream));
+                SHCHK(enqueue_forest_reduce(c, (const digest64*)digA, (digest64*)digB, (digest64*)digA, ilog2(L) - K, B, rec, gen));
+            }
+        } else {
             const size_t half = L / 2;
-            fp* next = keep ? (fp*)arena + (N - L) : (fp*)((r & 1) ? bufY : bufX);         // arena: round r+1 at offset N - N/2^r (L = N/2^r)
+            fp* next = keep ? (fp*)arena + (N - L) : (fp*)(((r - 1) & 1) ? bufY : bufX);   // arena: round r at offset N - N/2^(r-1) (L = N/2^(r-1))
             if (keep) keep->push_back(next);
-            uint32_t K = leaf_subtree_k(ilog2(half));
-            void* dig;
-            SHCHK(ensure_scratch(c, SCR_DIG_A, (half >> K) * sizeof(digest64), &dig));
-            const auto t1 = now();
-            HIPCHK(launch_fold_leaf_subtree(cur, L, 1, nullptr, fp_to_mont(c0), tw_inv, log_N, r, next, (digest64*)dig, K, c->stream));
-            const auto t2 = now();
-            SHCHK(reduce_digests(c, (const digest64*)dig, half >> K));
-            const auto t3 = now();
-            SHCHK(fetch_root(c, root));
-            if (dbg) fprintf(stderr, "[stark_hip] round %2u L=2^%-2u  cb+c0 %5.1f us | launch fold %5.1f | launch reduce %5.1f | wait root %6.1f\n",
-                             r, ilog2(L), us(t0, t1), us(t1, t2), us(t2, t3), us(t3, now()));
+            guard.waits = r;
+            if (use_round_wg && B * half <= ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL)) SHCHK(small_round(true, cur, next, ilog2(half)));
+            else {
+                HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)),
+                                      (fp*)d_c0, B, d_abort, hd_abort, timeout_ticks, c->stream));
+                const uint32_t K = leaf_k(half);
+                HIPCHK(launch_fold_leaf_subtree(cur, L, B, (const fp*)d_c0, fp_zero(), tw_inv, log_N, r - 1, next, (digest64*)digA, K, c->stream));
+                SHCHK(enqueue_forest_reduce(c, (const digest64*)digA, (digest64*)digB, (digest64*)digA, ilog2(half) - K, B, rec, gen));
+            }
             cur = next; L = half;
+        }
+        ++enq;
+        if (enq == R && stage_last) HIPCHK(launch_copy_to_host(cur, reinterpret_cast<fp*>(c->d_chain + lay.off_last), B * L, c->stream));
+        return SH_OK;
+    };
+    SHCHK(enqueue_round());
+    if (R > 1) SHCHK(enqueue_round());
+
+    // ---- serve the chain: root_r -> transcript -> challenge_r -> fold constants
+    const fp inv2 = fp_inv(fp_make(2, 0, 0, 0));
+    fp off_inv = fp_inv(off);                      // (off^(2^r))^-1 = (off^-1)^(2^r): one inversion for the whole commit
+    std::vector<fp> alpha(B);
+    const bool dbg = getenv("STARK_HIP_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_wait = 0, t_host = 0, t_enq = 0;
+    for (uint32_t r = 0; r < R; ++r) {
+        const double t0 = now();
+        SHCHK(wait_seq(c, reinterpret_cast<const uint32_t*>(c->h_chain + lay.root_seq(r)), gen));
+        const double t1 = now();
+        const bool want = r + 1 < R;
+        SHCHK(fn(r, c->h_chain + lay.roots(r), want, alpha.data()));
+        if (want) {
+            fp* h_c0 = reinterpret_cast<fp*>(c->h_chain + lay.c0(r));
+            for (size_t b = 0; b < B; ++b) {
+                if (!fp_is_canonical(alpha[b])) return sh_fail(SH_EINVAL, "fri_commit: callback returned a non-canonical alpha");
+                h_c0[b] = fp_to_mont(fp_mul(fp_mul(alpha[b], inv2), off_inv));        // c0 = alpha · 2^-1 · offset_r^-1
+            }
+            __atomic_store_n(reinterpret_cast<uint32_t*>(c->h_chain + lay.c0_seq(r)), gen, __ATOMIC_RELEASE);
+            guard.next_c0 = r + 1;
             off_inv = fp_mul(off_inv, off_inv);
         }
+        const double t2 = now();
+        if (enq < R) SHCHK(enqueue_round());
+        if (dbg) {
+            const double t3 = now();
+            t_wait += t1 - t0; t_host += t2 - t1; t_enq += t3 - t2;
+            fprintf(stderr, "[stark_hip] round %2u L=2^%-2u  wait root %6.1f us | transcript + c0 %5.1f us | enqueue ahead %5.1f us\n", r, ilog2(N >> r), t1 - t0, t2 - t1, t3 - t2);
+        }
     }
-    HIPCHK(hipMemcpyAsync(last_out, cur, L * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
+    guard.armed = false;
+    if (!stage_last) HIPCHK(hipMemcpyAsync(last_out, cur, last_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (*h_abort) return sh_fail(SH_EHIP, "fri_commit: a round timed out on the GPU waiting for its challenge");
+    if (stage_last) memcpy(last_out, c->h_chain + lay.off_last, last_bytes);
     *last_len = L;
+    if (dbg) fprintf(stderr, "[stark_hip] commit B=%zu N=2^%u: waited for roots %.0f us, host transcripts %.0f us, enqueue %.0f us over %u rounds\n", B, log_N, t_wait, t_host, t_enq, R);
     return SH_OK;
+}
+
+int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_params* prm, sh_transcript_cb cb, void* user,
+                       uint8_t* roots_out, uint64_t* last_out, size_t* last_len, std::vector<const fp*>* keep) {
+    CTXCHK(c);
+    if (!d_cw || !cb || !roots_out || !last_out || !last_len) return sh_fail(SH_EINVAL, "fri_commit: null pointer");
+    if (!is_pow2(N)) return sh_fail(SH_EINVAL, "fri_commit: N must be a power of two");
+    if (ilog2(N) > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "fri_commit: N > 2^%d", SH_MAX_LOG_N);
+    try {
+        RoundFn fn = [&](uint32_t r, const uint8_t* roots, bool want, fp* alpha_out) -> int32_t {
+            memcpy(roots_out + 64 * (size_t)r, roots, 64);
+            uint64_t alpha_w[2] = {0, 0};
+            if (cb(user, r, roots_out + 64 * (size_t)r, want ? 1 : 0, alpha_w) != 0) return sh_failf(SH_ECALLBACK, "fri_commit: transcript callback failed in round %u", r);
+            if (want) alpha_out[0] = fp_load_host(alpha_w);
+            return SH_OK;
+        };
+        return fri_commit_core(c, d_cw, 1, N, prm, fn, last_out, last_len, keep);
+    } catch (const std::bad_alloc&) { return sh_fail(SH_ENOMEM, "fri_commit: out of host memory");
+    } catch (...) { return sh_fail(SH_ENOMEM, "fri_commit: unexpected exception on the host side"); }
 }
 
 // Worker threads that live for one batched commit and are handed one slice of the B transcripts per round.  They spin
@@ -123,45 +323,8 @@ class SpinPool {
 // ------------------------------------------------------------------ batched FRI commit (lock-step rounds)
 // B independent codewords of equal length, back to back.  Every kernel of a round covers all B codewords, so the
 // serial root -> challenge -> fold chain is paid once per round for the whole batch instead of
-// once per commit: this is what makes small commits (config 4: 1024 x 2^14) throughput-bound.
-// `via_mail`: when set and the last step is a quad reduction, the B roots go straight to the pinned host buffer
-// (c->d_hbatch) and the mailbox sequence number announces them (*via_mail = true); otherwise they land in d_roots.
-static int32_t reduce_digests_batch(sh_ctx* c, const digest64* cur, size_t count, size_t B, digest64* d_roots, bool* via_mail = nullptr) {
-    uint32_t lg = ilog2(count);
-    if (via_mail) *via_mail = false;
-    if (lg == 0) {
-        HIPCHK(hipMemcpyAsync(d_roots, cur, B * sizeof(digest64), hipMemcpyDeviceToDevice, c->stream));
-        return SH_OK;
-    }
-    bool use_b = true;
-    while (lg > 0) {
-        const size_t total = B << lg;
-        const bool wide = total > ((size_t)1 << QUAD_MAX_LOG_COUNT);
-        uint32_t step;
-        if (wide) {                            // lane-per-subtree levels only down to what the quad kernel takes (2^17 digests in all)
-            const uint32_t over = ilog2(total) - QUAD_MAX_LOG_COUNT;
-            step = over < 3 ? over : 3;
-            if (step > lg) step = lg;
-        } else step = lg < QUAD_MAX_LOG_CHUNK ? lg : QUAD_MAX_LOG_CHUNK;
-        digest64* out = d_roots;
-        if (lg != step) {
-            void* b;
-            SHCHK(ensure_scratch(c, use_b ? SCR_DIG_B : SCR_DIG_A, (total >> step) * sizeof(digest64), &b));
-            use_b = !use_b;
-            out = (digest64*)b;
-        }
-        if (wide) HIPCHK(launch_node_subtree(cur, out, total >> step, step, c->stream));
-        else if (lg == step && via_mail && c->d_hbatch) {
-            if (++c->mail_seq == 0) c->mail_seq = 1;
-            c->batch_done_total += (uint32_t)B;
-            HIPCHK(launch_quad_reduce(cur, (digest64*)c->d_hbatch, total, step, c->d_mail, c->mail_seq, c->stream, c->d_flag + 16, c->batch_done_total));
-            *via_mail = true;
-        } else HIPCHK(launch_quad_reduce(cur, out, total, step, nullptr, 0, c->stream));
-        cur = out; lg -= step;
-    }
-    return SH_OK;
-}
-
+// once per commit: this is what makes small commits (config 4: 1024 x 2^14) throughput-bound.  Each codeword has its
+// own ProofStream; a spin pool advances the B transcripts of a round in parallel.
 static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t N, const sh_fri_params* prm, sh_proofstream** streams,
                                     uint8_t* roots_out, uint64_t* last_out, size_t* last_len) {
     CTXCHK(c);
@@ -171,69 +334,19 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
     if (!is_pow2(N)) return sh_fail(SH_EINVAL, "fri_commit_batch: N must be a power of two");
     const uint32_t log_N = ilog2(N);
     if (log_N > SH_MAX_LOG_N || ilog2(B) + log_N > 30) return sh_fail(SH_EINVAL, "fri_commit_batch: batch too large (B*N must be <= 2^30)");
-    fp off;
-    SHCHK(check_params(prm, &off));
+    if (!prm) return sh_fail(SH_EINVAL, "fri: null params");
     const uint32_t R = sh_fri_num_rounds(N, prm->expansion, prm->num_colinearity_tests);
-    const fp* cur = d_cws;
-    size_t L = N;
-    if (R > 0) {
-        const fp* tw_inv;
-        SHCHK(get_twiddles(c, log_N, true, &tw_inv));
-        void *bufX = nullptr, *bufY = nullptr, *d_roots, *d_c0;
-        if (R > 1) SHCHK(ensure_scratch(c, SCR_IO_A, B * (N / 2) * sizeof(fp), &bufX));
-        if (R > 2) SHCHK(ensure_scratch(c, SCR_IO_B, B * (N / 4) * sizeof(fp), &bufY));
-        SHCHK(ensure_scratch(c, SCR_ROOTS, B * sizeof(digest64), &d_roots));
-        SHCHK(ensure_scratch(c, SCR_C0, B * sizeof(fp), &d_c0));
-        const size_t L_last = N >> (R - 1);
-        const size_t need = B * 64 + B * 16 + B * L_last * sizeof(fp);     // roots | c0 | last codewords
-        if (c->h_batch_bytes < need) {
-            if (c->h_batch) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->h_batch)); c->h_batch = nullptr; c->d_hbatch = nullptr; c->h_batch_bytes = 0; }
-            HIPCHK(hipHostMalloc((void**)&c->h_batch, need, hipHostMallocMapped | hipHostMallocCoherent));
-            HIPCHK(hipHostGetDevicePointer((void**)&c->d_hbatch, c->h_batch, 0));
-            c->h_batch_bytes = need;
-        }
-        uint8_t* h_roots = c->h_batch;
-        fp* h_c0 = reinterpret_cast<fp*>(c->h_batch + B * 64);
-        const fp* d_c0_host = reinterpret_cast<const fp*>(c->d_hbatch + B * 64);   // the fold kernel reads c0[b] straight from pinned memory
-        bool via_mail = false;
-        (void)d_c0;
-        const fp inv2 = fp_inv(fp_make(2, 0, 0, 0));
-        fp off_inv = fp_inv(off);
-        auto leaf_k = [&](size_t len) {                 // per-lane subtree depth: fill the chip first, never cross a codeword
-            uint32_t K = leaf_subtree_k(ilog2(B * len));
-            const uint32_t lg = ilog2(len);
-            return K < lg ? K : lg;
-        };
-        {
-            const uint32_t K = leaf_k(L);
-            void* dig;
-            SHCHK(ensure_scratch(c, SCR_DIG_A, ((B * L) >> K) * sizeof(digest64), &dig));
-            HIPCHK(launch_leaf_subtree(cur, (digest64*)dig, (B * L) >> K, K, c->stream));
-            SHCHK(reduce_digests_batch(c, (const digest64*)dig, L >> K, B, (digest64*)d_roots, &via_mail));
-        }
+    try {
         unsigned T = std::thread::hardware_concurrency();
         if (T > 8) T = 8;
         if (T > B / 16) T = (unsigned)(B / 16);
-        SpinPool pool(T > 1 ? T - 1 : 0);
-        const bool dbg = getenv("STARK_HIP_DEBUG") != nullptr;
-        double t_wait = 0, t_host = 0, t_launch = 0;
-        auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        for (uint32_t r = 0; r < R; ++r) {
-            const double t0 = now();
-            bool got = false;
-            if (via_mail) SHCHK(wait_mailbox(c, &got));
-            if (!got) {
-                if (via_mail) ++c->mail_fallbacks;
-                if (!via_mail) HIPCHK(hipMemcpyAsync(h_roots, d_roots, B * 64, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(hipStreamSynchronize(c->stream));          // (via_mail: the stream drained, so the roots are already in h_roots)
-            }
-            const double t1 = now();
-            t_wait += t1 - t0;
-            const bool want = r + 1 < R;
+        std::unique_ptr<SpinPool> pool;
+        try { pool.reset(new SpinPool(T > 1 ? T - 1 : 0)); } catch (const std::system_error&) { pool.reset(new SpinPool(0)); }   // no threads to be had: the caller does it all
+        RoundFn fn = [&](uint32_t r, const uint8_t* roots, bool want, fp* alpha_out) -> int32_t {
             std::atomic<int> failed{0};
             auto per_codeword = [&](size_t b0, size_t b1) {          // transcripts are independent: one ProofStream per codeword
                 for (size_t b = b0; b < b1; ++b) {
-                    const uint8_t* root = h_roots + 64 * b;
+                    const uint8_t* root = roots + 64 * b;
                     memcpy(roots_out + 64 * (b * R + r), root, 64);
                     if (sh_proofstream_push_merkle_root(streams[b], root) != SH_OK) { failed = 1; return; }      // proof_stream.rs:25
                     if (want) {
@@ -241,57 +354,26 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
                         uint64_t aw[2];
                         if (sh_proofstream_prover_fiat_shamir(streams[b], dig) != SH_OK) { failed = 1; return; } // proof_stream.rs:51
                         if (sh_sample_field(dig, aw) != SH_OK) { failed = 1; return; }                           // G3
-                        h_c0[b] = fp_to_mont(fp_mul(fp_mul(fp_load_host(aw), inv2), off_inv));
+                        alpha_out[b] = fp_load_host(aw);
                     }
                 }
             };
-            pool.parallel(B, per_codeword);
-            if (failed) return sh_fail(SH_ECALLBACK, "fri_commit_batch: transcript update failed");
-            t_host += now() - t1;
-            if (!want) { if (dbg) fprintf(stderr, "[stark_hip] batch B=%zu N=%zu: wait %.0f us, host transcript %.0f us, launches %.0f us over %u rounds\n", B, N, t_wait, t_host, t_launch, R); break; }
-            const double t2 = now();
-            const size_t half = L / 2;
-            fp* next = (fp*)((r & 1) ? bufY : bufX);
-            const uint32_t K = leaf_k(half);
-            void* dig;
-            SHCHK(ensure_scratch(c, SCR_DIG_A, ((B * half) >> K) * sizeof(digest64), &dig));
-            HIPCHK(launch_fold_leaf_subtree(cur, L, B, d_c0_host, fp_zero(), tw_inv, log_N, r, next, (digest64*)dig, K, c->stream));
-            SHCHK(reduce_digests_batch(c, (const digest64*)dig, half >> K, B, (digest64*)d_roots, &via_mail));
-            cur = next; L = half;
-            off_inv = fp_mul(off_inv, off_inv);
-            t_launch += now() - t2;
-        }
-    }
-    const auto t_tail0 = std::chrono::steady_clock::now();
-    if (R > 0 && c->h_batch && c->h_batch_bytes >= B * 80 + B * L * sizeof(fp)) {       // through pinned staging: a pageable D2H is several times slower
-        uint8_t* stage = c->h_batch + B * 80;
-        HIPCHK(hipMemcpyAsync(stage, cur, B * L * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        memcpy(last_out, stage, B * L * sizeof(fp));
-    } else {
-        HIPCHK(hipMemcpyAsync(last_out, cur, B * L * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
-    *last_len = L;
-    {
+            pool->parallel(B, per_codeword);
+            return failed ? sh_fail(SH_ECALLBACK, "fri_commit_batch: transcript update failed") : SH_OK;
+        };
+        const auto t_core0 = std::chrono::steady_clock::now();
+        SHCHK(fri_commit_core(c, d_cws, B, N, prm, fn, last_out, last_len, nullptr));
+        const auto t_tail0 = std::chrono::steady_clock::now();
+        const size_t L = *last_len;
         std::atomic<int> failed{0};
-        auto push = [&](size_t b0, size_t b1) { for (size_t b = b0; b < b1; ++b) if (sh_proofstream_push_codeword(streams[b], last_out + 2 * b * L, L) != SH_OK) failed = 1; };
-        unsigned T = std::thread::hardware_concurrency();
-        if (T > 16) T = 16;
-        if (T > B / 16) T = (unsigned)(B / 16);
-        if (T <= 1) push(0, B);
-        else {
-            std::vector<std::thread> th;
-            const size_t chunk = (B + T - 1) / T;
-            for (unsigned t = 1; t < T; ++t) th.emplace_back(push, t * chunk < B ? t * chunk : B, (t + 1) * chunk < B ? (t + 1) * chunk : B);
-            push(0, chunk < B ? chunk : B);
-            for (auto& x : th) x.join();
-        }
+        pool->parallel(B, [&](size_t b0, size_t b1) { for (size_t b = b0; b < b1; ++b) if (sh_proofstream_push_codeword(streams[b], last_out + 2 * b * L, L) != SH_OK) failed = 1; });
         if (failed) return sh_fail(SH_ECALLBACK, "fri_commit_batch: pushing the last codeword failed");
-    }
-    if (getenv("STARK_HIP_DEBUG")) fprintf(stderr, "[stark_hip] batch tail (last codewords to host + push): %.0f us\n",
-                                           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_tail0).count());
-    return SH_OK;
+        if (getenv("STARK_HIP_DEBUG")) fprintf(stderr, "[stark_hip] batch: rounds %.0f us, pushing the last codewords %.0f us\n",
+                                               std::chrono::duration<double, std::micro>(t_tail0 - t_core0).count(),
+                                               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_tail0).count());
+        return SH_OK;
+    } catch (const std::bad_alloc&) { return sh_fail(SH_ENOMEM, "fri_commit_batch: out of host memory");
+    } catch (...) { return sh_fail(SH_ENOMEM, "fri_commit_batch: unexpected exception on the host side"); }
 }
 
 int32_t ps_callback(void* user, uint32_t, const uint8_t root[64], int32_t want_alpha, uint64_t alpha_out[2]) {

@@ -10,6 +10,8 @@
 #include <chrono>
 #include <functional>
 #include <map>
+#include <memory>
+#include <system_error>
 #include <new>
 #include <atomic>
 #include <string>
@@ -56,6 +58,10 @@ struct sh_ctx {
     uint8_t* d_hbatch = nullptr;                 // device view of h_batch
     size_t h_batch_bytes = 0;
     uint32_t batch_done_total = 0;               // running total of workgroups that have reported through d_flag[16]
+    uint8_t* h_chain = nullptr;                  // pinned, device-mapped: root / fold-constant records of a commit's rounds (api_fri.hip)
+    uint8_t* d_chain = nullptr;                  // device view of h_chain
+    size_t chain_bytes = 0;
+    uint32_t chain_gen = 0;                      // generation number of the last commit (the records' sequence value)
 };
 
 static inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }

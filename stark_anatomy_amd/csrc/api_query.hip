@@ -45,7 +45,8 @@ static uint64_t sample_index(const uint8_t* bytes, size_t n, uint64_t size) {
 static int32_t sample_indices(const uint8_t seed[32], uint64_t size, uint64_t reduced_size, uint32_t number, std::vector<uint64_t>* out) {
     out->clear();
     if (size == 0 || reduced_size == 0) return sh_fail(SH_EINVAL, "sample_indices: empty domain");
-    if (number > reduced_size) return sh_failf(SH_EINVAL, "sample_indices: cannot sample %u indices with distinct residues mod %llu", number, (unsigned long long)reduced_size);
+    if (number > reduced_size || number > size)          // only min(size, reduced_size) distinct residues exist: the loop below would never end
+        return sh_failf(SH_EINVAL, "sample_indices: cannot sample %u indices below %llu with distinct residues mod %llu", number, (unsigned long long)size, (unsigned long long)reduced_size);
     std::vector<uint64_t> reduced;
     uint8_t buf[40], dig[64];
     memcpy(buf, seed, 32);
@@ -65,6 +66,8 @@ static int32_t fri_prove_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_p
     if (!ps || !n_top) return sh_fail(SH_EINVAL, "fri_prove: null pointer");
     *n_top = 0;
     if (!prm) return sh_fail(SH_EINVAL, "fri: null params");
+    if (!d_cw) return sh_fail(SH_EINVAL, "fri_prove: null codeword");
+    if (!is_pow2(N) || ilog2(N) > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "fri_prove: N must be a power of two <= 2^%d", SH_MAX_LOG_N);   // before anything is sized from N
     const uint32_t t = prm->num_colinearity_tests;
     const uint32_t R = sh_fri_num_rounds(N, prm->expansion, t);
     std::vector<uint8_t> roots((size_t)(R ? R : 1) * 64);
@@ -172,16 +175,25 @@ int32_t sh_merkle_open_batch(sh_ctx* c, const uint8_t* leaves, size_t L, const u
     return gather_paths_to_host(c, (const digest64*)lv, L, indices, n_idx, paths);
 }
 int32_t sh_fri_sample_indices(const uint8_t seed[32], uint64_t size, uint64_t reduced_size, uint32_t number, uint64_t* out) {
+    try {
     if (!seed || (!out && number)) return sh_fail(SH_EINVAL, "sh_fri_sample_indices: null pointer");
     std::vector<uint64_t> v;
     SHCHK(sample_indices(seed, size, reduced_size, number, &v));
     memcpy(out, v.data(), v.size() * 8);
     return SH_OK;
+    } catch (const std::bad_alloc&) { return sh_fail(SH_ENOMEM, "sh_fri_sample_indices: out of host memory"); } catch (...) { return sh_fail(SH_ENOMEM, "sh_fri_sample_indices: unexpected exception on the host side"); }
+}
+// nothing unwinds through the C ABI: host-side allocation failures come back as SH_ENOMEM
+static int32_t fri_prove_guarded(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_params* params, sh_proofstream* ps, uint64_t* top, size_t* n_top) {
+    try { return fri_prove_dev(c, d_cw, N, params, ps, top, n_top); }
+    catch (const std::bad_alloc&) { return sh_fail(SH_ENOMEM, "fri_prove: out of host memory"); }
+    catch (...) { return sh_fail(SH_ENOMEM, "fri_prove: unexpected exception on the host side"); }
 }
 int32_t sh_dev_fri_prove(sh_ctx* c, const uint64_t* d_codeword, size_t N, const sh_fri_params* params, sh_proofstream* ps,
                          uint64_t* top_level_indices, size_t* n_indices) {
-    return fri_prove_dev(c, (const fp*)d_codeword, N, params, ps, top_level_indices, n_indices);
+    return fri_prove_guarded(c, (const fp*)d_codeword, N, params, ps, top_level_indices, n_indices);
 }
+const char* sh_fri_proof_format(void) { return "stark-anat-fri/1"; }
 int32_t sh_fri_prove(sh_ctx* c, const uint64_t* codeword, size_t N, const sh_fri_params* params, sh_proofstream* ps,
                      uint64_t* top_level_indices, size_t* n_indices) {
     CTXCHK(c);
@@ -190,12 +202,13 @@ int32_t sh_fri_prove(sh_ctx* c, const uint64_t* codeword, size_t N, const sh_fri
     void* d;
     SHCHK(ensure_scratch(c, SCR_IO_C, N * 16, &d));
     HIPCHK(hipMemcpyAsync(d, codeword, N * 16, hipMemcpyHostToDevice, c->stream));
-    return fri_prove_dev(c, (const fp*)d, N, params, ps, top_level_indices, n_indices);
+    return fri_prove_guarded(c, (const fp*)d, N, params, ps, top_level_indices, n_indices);
 }
 
 // G12: the verifier.  Host only ("CPU-side is enough"): ~R·3t path checks of log2 L compressions.
 // Reads the stream from its read index.  *accepted = 1/0; on 0, sh_last_error() says which check failed.
 int32_t sh_fri_verify(sh_proofstream* ps, size_t N, const sh_fri_params* prm, int32_t* accepted, uint64_t* top_level_indices, size_t* n_indices) {
+    try {
     if (!ps || !accepted) return sh_fail(SH_EINVAL, "sh_fri_verify: null pointer");
     *accepted = 0;
     if (n_indices) *n_indices = 0;
@@ -282,6 +295,7 @@ int32_t sh_fri_verify(sh_proofstream* ps, size_t N, const sh_fri_params* prm, in
     }
     *accepted = 1;
     return SH_OK;
+    } catch (const std::bad_alloc&) { return sh_fail(SH_ENOMEM, "sh_fri_verify: out of host memory"); } catch (...) { return sh_fail(SH_ENOMEM, "sh_fri_verify: unexpected exception on the host side"); }
 }
 
 }  // extern "C"

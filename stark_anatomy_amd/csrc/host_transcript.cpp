@@ -280,6 +280,12 @@ struct JsonScan {
 };
 }  // namespace
 
+// Nothing unwinds through the C ABI: an allocation failure inside an entry point comes back as SH_ENOMEM.
+#define SH_GUARD_BEGIN try {
+#define SH_GUARD_END(name)                                                                                  \
+    } catch (const std::bad_alloc&) { return sh_fail(SH_ENOMEM, name ": out of host memory");               \
+    } catch (...) { return sh_fail(SH_ENOMEM, name ": unexpected exception on the host side"); }
+
 extern "C" {
 
 int32_t sh_sha256(const uint8_t* in, size_t len, uint8_t out[32]) {
@@ -316,11 +322,14 @@ int32_t sh_proofstream_new(sh_proofstream** out) {
 }
 int32_t sh_proofstream_free(sh_proofstream* ps) { delete ps; return SH_OK; }
 int32_t sh_proofstream_push_json(sh_proofstream* ps, const uint8_t* json, size_t len) {       // proof_stream.rs:25-27
+    SH_GUARD_BEGIN
     if (!ps || (!json && len)) return sh_fail(SH_EINVAL, "sh_proofstream_push_json: null pointer");
     ps->items.emplace_back((const char*)json, len);
     return SH_OK;
+    SH_GUARD_END("sh_proofstream_push_json")
 }
 int32_t sh_proofstream_push_merkle_root(sh_proofstream* ps, const uint8_t root[64]) {         // merkle.rs:9-13 shape
+    SH_GUARD_BEGIN
     if (!ps || !root) return sh_fail(SH_EINVAL, "sh_proofstream_push_merkle_root: null pointer");
     char buf[24 + 64 * 4 + 4];
     size_t o = 24;
@@ -329,8 +338,10 @@ int32_t sh_proofstream_push_merkle_root(sh_proofstream* ps, const uint8_t root[6
     memcpy(buf + o, "]}}", 3);
     ps->items.emplace_back(buf, o + 3);
     return SH_OK;
+    SH_GUARD_END("sh_proofstream_push_merkle_root")
 }
 int32_t sh_proofstream_push_codeword(sh_proofstream* ps, const uint64_t* elems, size_t n) {
+    SH_GUARD_BEGIN
     if (!ps || (!elems && n)) return sh_fail(SH_EINVAL, "sh_proofstream_push_codeword: null pointer");
     std::string s(13 + n * 40 + 2, '\0');
     char* buf = &s[0];
@@ -344,10 +355,12 @@ int32_t sh_proofstream_push_codeword(sh_proofstream* ps, const uint64_t* elems, 
     s.resize(o);
     ps->items.push_back(std::move(s));
     return SH_OK;
+    SH_GUARD_END("sh_proofstream_push_codeword")
 }
 // Query-phase items: {"Leaves":[a,b,c]} — the three codeword values of one colinearity test — and
 // {"Path":[{"inner":[..]},..]} — a Merkle authentication path, Vec<MerkleHash> as serde writes it (merkle.rs:9-13).
 int32_t sh_proofstream_push_leaves(sh_proofstream* ps, const uint64_t* elems, size_t n) {
+    SH_GUARD_BEGIN
     if (!ps || (!elems && n)) return sh_fail(SH_EINVAL, "sh_proofstream_push_leaves: null pointer");
     std::string s(11 + n * 40 + 2, '\0');
     char* buf = &s[0];
@@ -361,8 +374,10 @@ int32_t sh_proofstream_push_leaves(sh_proofstream* ps, const uint64_t* elems, si
     s.resize(o);
     ps->items.push_back(std::move(s));
     return SH_OK;
+    SH_GUARD_END("sh_proofstream_push_leaves")
 }
 int32_t sh_proofstream_push_path(sh_proofstream* ps, const uint8_t* digests, size_t n) {
+    SH_GUARD_BEGIN
     if (!ps || (!digests && n)) return sh_fail(SH_EINVAL, "sh_proofstream_push_path: null pointer");
     std::string s(9 + n * (10 + 64 * 4 + 3) + 2, '\0');
     char* buf = &s[0];
@@ -378,6 +393,7 @@ int32_t sh_proofstream_push_path(sh_proofstream* ps, const uint8_t* digests, siz
     s.resize(o);
     ps->items.push_back(std::move(s));
     return SH_OK;
+    SH_GUARD_END("sh_proofstream_push_path")
 }
 int32_t sh_proofstream_len(sh_proofstream* ps, size_t* n_items, size_t* read_index) {
     if (!ps) return sh_fail(SH_EINVAL, "sh_proofstream_len: null pointer");
@@ -394,14 +410,17 @@ int32_t sh_proofstream_pull(sh_proofstream* ps, const uint8_t** json, size_t* le
     return SH_OK;
 }
 int32_t sh_proofstream_serialize(sh_proofstream* ps, uint8_t* out, size_t cap, size_t* needed) {   // proof_stream.rs:38-40
+    SH_GUARD_BEGIN
     if (!ps || !needed) return sh_fail(SH_EINVAL, "sh_proofstream_serialize: null pointer");
     std::string s = serialize_items(ps->items, ps->items.size());
     *needed = s.size();
     if (out && cap >= s.size()) memcpy(out, s.data(), s.size());
     else if (out) return sh_fail(SH_EINVAL, "sh_proofstream_serialize: buffer too small");
     return SH_OK;
+    SH_GUARD_END("sh_proofstream_serialize")
 }
 int32_t sh_proofstream_deserialize(const uint8_t* bytes, size_t len, sh_proofstream** out) {       // proof_stream.rs:42-49
+    SH_GUARD_BEGIN
     if (!bytes || !out) return sh_fail(SH_EINVAL, "sh_proofstream_deserialize: null pointer");
     JsonScan sc{bytes, bytes + len};
     sc.ws();
@@ -428,6 +447,7 @@ int32_t sh_proofstream_deserialize(const uint8_t* bytes, size_t len, sh_proofstr
     if (!ok || sc.p != sc.end) { delete ps; return sh_fail(SH_EPARSE, "Serialization error: malformed JSON"); }
     *out = ps;
     return SH_OK;
+    SH_GUARD_END("sh_proofstream_deserialize")
 }
 int32_t sh_proofstream_prover_fiat_shamir(sh_proofstream* ps, uint8_t out[32]) {                   // proof_stream.rs:51-56
     if (!ps || !out) return sh_fail(SH_EINVAL, "sh_proofstream_prover_fiat_shamir: null pointer");
@@ -448,10 +468,12 @@ int32_t sh_proofstream_prover_fiat_shamir(sh_proofstream* ps, uint8_t out[32]) {
     return SH_OK;
 }
 int32_t sh_proofstream_verifier_fiat_shamir(sh_proofstream* ps, uint8_t out[32]) {                 // proof_stream.rs:58-64
+    SH_GUARD_BEGIN
     if (!ps || !out) return sh_fail(SH_EINVAL, "sh_proofstream_verifier_fiat_shamir: null pointer");
     std::string s = serialize_items(ps->items, ps->read_index);
     host_sha256((const uint8_t*)s.data(), s.size(), out);
     return SH_OK;
+    SH_GUARD_END("sh_proofstream_verifier_fiat_shamir")
 }
 
 }  // extern "C"

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time sh_dev_fri_commit_batch for B x 2^log_n, with the ProofStream objects created outside the timed call."""
-import ctypes as C, sys, time
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import stark_anatomy_amd as sa
 from stark_anatomy_amd import _lib
