@@ -52,6 +52,9 @@ const char* sh_version(void);
  * (e.g. torch.cuda.current_stream().cuda_stream) on `device`. */
 int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out);
 int32_t sh_ctx_destroy(sh_ctx* ctx);
+/* Diagnostics: rounds that the FRI commit driver had to enqueue a second time on this context so far (see the commit driver
+ * below); 0 in normal operation. */
+uint64_t sh_ctx_chain_retries(const sh_ctx* ctx);
 int32_t sh_ctx_sync(sh_ctx* ctx);
 int32_t sh_ctx_device(sh_ctx* ctx, int32_t* device);
 int32_t sh_dev_alloc(sh_ctx* ctx, size_t bytes, void** dptr);
@@ -147,7 +150,12 @@ int32_t sh_dev_scale_powers(sh_ctx* ctx, uint64_t* d_data, size_t count, uint64_
  * R = sh_fri_num_rounds(N, expansion, num_colinearity_tests); the last round's codeword (length
  * N >> (R-1)) is returned in the clear.  The transcript stays on the host: the callback receives
  * every root in order and (when want_alpha != 0) must return the challenge, so the caller's
- * `ProofStream` (proof_stream.rs:25-27, 51-56) remains authoritative and byte-identical. */
+ * `ProofStream` (proof_stream.rs:25-27, 51-56) remains authoritative and byte-identical.
+ * While a callback runs, the next round's kernel is already on the GPU waiting for the challenge it returns.  That wait is a
+ * bounded spin (STARK_HIP_CHAIN_SPIN_US, default 500): a kernel that runs out abandons its round, the kernels behind it return
+ * at once, and the driver enqueues the round again when the challenge is there — so a slow callback, or one that waits for
+ * this GPU, costs at most one spin budget plus a re-launch per round, not the commit.  sh_ctx_chain_retries() counts these.
+ * A root that does not arrive within STARK_HIP_CHAIN_TIMEOUT_S (default 20 s) fails the commit with SH_EHIP. */
 typedef struct {
     uint32_t expansion;                 /* 4 in every reference configuration            */
     uint32_t num_colinearity_tests;     /* 17                                            */

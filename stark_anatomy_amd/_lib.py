@@ -52,6 +52,7 @@ _PROTOS = {
     "sh_version": (C.c_char_p, []),
     "sh_ctx_create": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(ctx_t)]),
     "sh_ctx_destroy": (C.c_int32, [ctx_t]),
+    "sh_ctx_chain_retries": (C.c_uint64, [ctx_t]),
     "sh_ctx_sync": (C.c_int32, [ctx_t]),
     "sh_ctx_device": (C.c_int32, [ctx_t, C.POINTER(C.c_int32)]),
     "sh_dev_alloc": (C.c_int32, [ctx_t, C.c_size_t, C.POINTER(C.c_void_p)]),

@@ -88,6 +88,12 @@ class Context:
         self.device = int(device)
 
     def sync(self): check(lib.sh_ctx_sync(self.handle))
+
+    @property
+    def chain_retries(self):
+        """rounds the FRI commit driver had to enqueue a second time on this context (stark_hip.h: sh_ctx_chain_retries)"""
+        return int(lib.sh_ctx_chain_retries(self.handle))
+
     def alloc(self, nbytes): return DeviceBuffer(self, nbytes)
 
     def upload_elems(self, vals):

@@ -94,6 +94,7 @@ int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out) {
     *out = c;
     return SH_OK;
 }
+uint64_t sh_ctx_chain_retries(const sh_ctx* c) { return c ? c->chain_retries : 0; }
 int32_t sh_ctx_destroy(sh_ctx* c) {
     if (!c) return SH_OK;
     (void)hipSetDevice(c->device);

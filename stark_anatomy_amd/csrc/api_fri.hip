@@ -53,28 +53,44 @@ struct ChainGuard {
         (void)hipStreamSynchronize(c->stream);
     }
 };
-static int32_t wait_seq(sh_ctx* c, const uint32_t* flag, uint32_t gen) {
+// Wait for a root record.  NO HIP call on this path: while the host sits here the next round's kernel may already be spinning
+// on the GPU for the challenge this thread is about to produce, and a runtime call can block behind another thread's call
+// that itself waits for GPU work queued behind that spinning kernel (seen with two contexts in two threads).  So: poll the
+// record, the abort word that a wait kernel raises when its bounded spin runs out, and a wall clock.
+// Returns SH_OK, WAIT_RETRY (a wait kernel gave up: the caller re-enqueues from this round) or an error.
+static const int32_t WAIT_RETRY = 1;
+static int32_t wait_seq(sh_ctx* c, const uint32_t* flag, uint32_t gen, uint32_t round, double deadline_s) {
+    const volatile uint32_t* hd = reinterpret_cast<volatile uint32_t*>(c->h_chain);
+    const auto t0 = std::chrono::steady_clock::now();
     uint64_t spins = 0;
     for (;;) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == gen) return SH_OK;
-        if ((++spins & 0x3fff) == 0) {
-            hipError_t e = hipStreamQuery(c->stream);
-            if (e == hipSuccess) {
+        if ((++spins & 0xff) == 0) {
+            if (hd[0]) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == gen ? SH_OK : WAIT_RETRY;
+            if ((spins & 0x3ff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadline_s) {
+                const hipError_t e = hipStreamQuery(c->stream);
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == gen) return SH_OK;
-                return sh_fail(SH_EHIP, "fri_commit: the stream drained without publishing a Merkle root (a round timed out waiting for its challenge?)");
+                return sh_failf(SH_EHIP, "fri_commit: no Merkle root for round %u after %.0f s (stream: %s)", round, deadline_s,
+                                e == hipSuccess ? "drained" : hipGetErrorString(e));
             }
-            if (e != hipErrorNotReady) return sh_failf(SH_EHIP, "stream failed while waiting for a Merkle root: %s", hipGetErrorString(e));
         }
         __builtin_ia32_pause();
     }
 }
+// what the wait kernel that gave up last left in the chain header (round_kernels.hip)
+static int32_t fail_gave_up(sh_ctx* c, uint32_t round, uint32_t gen, uint32_t retries) {
+    const volatile uint32_t* hd = reinterpret_cast<volatile uint32_t*>(c->h_chain);
+    return sh_failf(SH_EHIP, "fri_commit: round %u: the GPU still does not see its challenge after %u re-launches (gen %u; kernel waited for gen %u, record held %u, chain offset 0x%x%s, "
+                    "block %u of %u, %u polls, xcc %u; the host sees %u there now)", round, retries, gen, hd[1], hd[2], hd[3] & 0x7fffffffu, (hd[3] >> 31) ? " [k_round_wg]" : " [k_wait_c0]",
+                    hd[4] & 0xffff, hd[4] >> 16, hd[5], hd[6], *reinterpret_cast<volatile uint32_t*>(c->h_chain + (hd[3] & 0x7fffffffu)));
+}
 
 // Forest reduction: B trees of 2^lg digests each, back to back at `cur` -> B roots in the round's record + sequence word.
 // Wide levels: one 2^K-node subtree per lane; from 2^17 digests down: four lanes per compression, levels in LDS.
-static int32_t enqueue_forest_reduce(sh_ctx* c, const digest64* cur, digest64* other, digest64* self, uint32_t lg, size_t B, uint8_t* d_rec, uint32_t gen) {
+static int32_t enqueue_forest_reduce(sh_ctx* c, const digest64* cur, digest64* other, digest64* self, uint32_t lg, size_t B, uint8_t* d_rec, uint32_t gen, const uint32_t* d_abort) {
     uint64_t* rec_roots = reinterpret_cast<uint64_t*>(d_rec);
     uint32_t* rec_seq = reinterpret_cast<uint32_t*>(d_rec + B * 64);
-    if (lg == 0) { HIPCHK(launch_publish_digests(cur, B, rec_roots, rec_seq, gen, c->stream)); return SH_OK; }
+    if (lg == 0) { HIPCHK(launch_publish_digests(cur, B, rec_roots, rec_seq, gen, c->stream, d_abort)); return SH_OK; }
     while (lg > 0) {
         const size_t total = B << lg;
         digest64* out = other;
@@ -85,22 +101,22 @@ static int32_t enqueue_forest_reduce(sh_ctx* c, const digest64* cur, digest64* o
             if (step > lg) step = lg;
             if (step == lg) {                                      // B > 2^17 trees: finish them lane-per-subtree, then publish
                 HIPCHK(launch_node_subtree(cur, out, total >> step, step, c->stream));
-                HIPCHK(launch_publish_digests(out, B, rec_roots, rec_seq, gen, c->stream));
+                HIPCHK(launch_publish_digests(out, B, rec_roots, rec_seq, gen, c->stream, d_abort));
                 return SH_OK;
             }
             HIPCHK(launch_node_subtree(cur, out, total >> step, step, c->stream));
         } else {
             step = lg <= QUAD_MAX_LOG_CHUNK ? lg : (total >= ((size_t)1 << 14) ? QUAD_MAX_LOG_CHUNK : (lg + 1) / 2);   // full workgroups while there is work; balanced launches once it is latency only
             if (step == lg) {
-                if (B == 1) HIPCHK(launch_quad_reduce(cur, c->d_root, total, step, rec_roots, gen, c->stream));
+                if (B == 1) HIPCHK(launch_quad_reduce(cur, c->d_root, total, step, rec_roots, gen, c->stream, nullptr, 0, d_abort));
                 else {
                     c->batch_done_total += (uint32_t)B;
                     HIPCHK(launch_quad_reduce(cur, reinterpret_cast<digest64*>(d_rec), total, step, reinterpret_cast<uint64_t*>(d_rec + B * 64 - 64), gen, c->stream,
-                                              c->d_flag + 16, c->batch_done_total));
+                                              c->d_flag + 16, c->batch_done_total, d_abort));
                 }
                 return SH_OK;
             }
-            HIPCHK(launch_quad_reduce(cur, out, total, step, nullptr, 0, c->stream));
+            HIPCHK(launch_quad_reduce(cur, out, total, step, nullptr, 0, c->stream, nullptr, 0, d_abort));
         }
         cur = out; other = self; self = out; lg -= step;
     }
@@ -152,20 +168,27 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
     uint32_t gen = (c->chain_gen + 1) & 0x7fffffffu;
     if (gen == 0) gen = 1;
     c->chain_gen = gen;
-    static const double timeout_s = [] { const char* e = getenv("STARK_HIP_CHAIN_TIMEOUT_S"); double v = e ? atof(e) : 0; return v > 0 ? v : 20.0; }();
-    const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1e8);
+    // A wait kernel spins for at most `spin_us`, then abandons its round; the host re-enqueues from that round (below).  The
+    // wall-clock `timeout_s` bounds the whole wait for one root.
+    const double timeout_s = [] { const char* e = getenv("STARK_HIP_CHAIN_TIMEOUT_S"); double v = e ? atof(e) : 0; return v > 0 ? v : 20.0; }();
+    const double spin_us = [] { const char* e = getenv("STARK_HIP_CHAIN_SPIN_US"); double v = e ? atof(e) : 0; return v > 0 ? v : 500.0; }();
+    const uint64_t timeout_ticks = (uint64_t)(spin_us * 100.0) + 1;                   // s_memrealtime: 100 MHz
     uint32_t* d_abort = c->d_flag + 32;
     uint32_t* h_abort = reinterpret_cast<uint32_t*>(c->h_chain);
     uint32_t* hd_abort = reinterpret_cast<uint32_t*>(c->d_chain);
-    *h_abort = 0;
+    for (int i = 0; i < 8; ++i) h_abort[i] = 0;
     HIPCHK(hipMemsetAsync(d_abort, 0, 4, c->stream));
 
     // ---- enqueue rounds one ahead of the chain: round r+1's kernels (which start by waiting for challenge r) are on the
     // stream before root r is picked up, and round r+2 is enqueued while the GPU works on round r+1.
+    // Round r >= 1 reads codeword r-1 (length N >> (r-1)) and writes codeword r; both are functions of r alone, so that a
+    // round can be enqueued a second time after its wait kernel gave up.
     ChainGuard guard{c, &lay, gen};
     guard.armed = true;
-    const fp* cur = d_cws;
-    size_t L = N;
+    auto cw_of = [&](uint32_t r) -> fp* {          // codeword r, r >= 1: arena offset N - N/2^(r-1), or the ping-pong buffers
+        return keep ? (fp*)arena + (N - (N >> (r - 1))) : (fp*)(((r - 1) & 1) ? bufY : bufX);
+    };
+    if (keep) for (uint32_t r = 1; r < R; ++r) keep->push_back(cw_of(r));
     uint32_t enq = 0;                              // rounds enqueued so far
     static const bool use_round_wg = getenv("STARK_NO_ROUND_WG") == nullptr;
     auto enqueue_round = [&]() -> int32_t {
@@ -176,7 +199,7 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
             const size_t blocks = ((B << lg_tree) + 127) / 128;
             uint32_t target = 0;
             if (lg_tree <= 7 && blocks > 1) { c->batch_done_total += (uint32_t)blocks; target = c->batch_done_total; }
-            const bool poll_inside = fold && B == 1 && blocks <= 32;       // else a wait kernel first: few lanes may touch host memory
+            const bool poll_inside = fold && B == 1 && blocks == 1;        // else a wait kernel first: exactly one workgroup ever polls host memory (round_kernels.hip)
             if (fold && !poll_inside)
                 HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)),
                                       (fp*)d_c0, B, d_abort, hd_abort, timeout_ticks, c->stream));
@@ -184,33 +207,32 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
                                    poll_inside ? reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)) : nullptr, (const fp*)d_c0, d_abort, hd_abort, timeout_ticks, tw_inv, log_N,
                                    fold ? r - 1 : 0, (digest64*)digA, reinterpret_cast<uint64_t*>(rec), reinterpret_cast<uint32_t*>(rec + B * 64), c->d_flag + 16, target,
                                    c->stream));
-            if (lg_tree > 7) SHCHK(enqueue_forest_reduce(c, (const digest64*)digA, (digest64*)digB, (digest64*)digA, lg_tree - 7, B, rec, gen));
+            if (lg_tree > 7) SHCHK(enqueue_forest_reduce(c, (const digest64*)digA, (digest64*)digB, (digest64*)digA, lg_tree - 7, B, rec, gen, d_abort));
             return SH_OK;
         };
         if (r == 0) {
-            if (use_round_wg && (B << log_N) <= ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL) && log_N >= 1) SHCHK(small_round(false, cur, nullptr, log_N));
+            if (use_round_wg && (B << log_N) <= ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL) && log_N >= 1) SHCHK(small_round(false, d_cws, nullptr, log_N));
             else {
-                const uint32_t K = leaf_k(L);
-                HIPCHK(launch_leaf_subtree(cur, (digest64*)digA, (B * L) >> K, K, c->stream));
-                SHCHK(enqueue_forest_reduce(c, (const digest64*)digA, (digest64*)digB, (digest64*)digA, ilog2(L) - K, B, rec, gen));
+                const uint32_t K = leaf_k(N);
+                HIPCHK(launch_leaf_subtree(d_cws, (digest64*)digA, (B * N) >> K, K, c->stream));
+                SHCHK(enqueue_forest_reduce(c, (const digest64*)digA, (digest64*)digB, (digest64*)digA, log_N - K, B, rec, gen, d_abort));
             }
         } else {
-            const size_t half = L / 2;
-            fp* next = keep ? (fp*)arena + (N - L) : (fp*)(((r - 1) & 1) ? bufY : bufX);   // arena: round r at offset N - N/2^(r-1) (L = N/2^(r-1))
-            if (keep) keep->push_back(next);
-            guard.waits = r;
-            if (use_round_wg && B * half <= ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL)) SHCHK(small_round(true, cur, next, ilog2(half)));
+            const size_t L = N >> (r - 1), half = L / 2;
+            const fp* in = r == 1 ? d_cws : cw_of(r - 1);
+            fp* next = cw_of(r);
+            if (guard.waits < r) guard.waits = r;
+            if (use_round_wg && B * half <= ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL)) SHCHK(small_round(true, in, next, ilog2(half)));
             else {
                 HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)),
                                       (fp*)d_c0, B, d_abort, hd_abort, timeout_ticks, c->stream));
                 const uint32_t K = leaf_k(half);
-                HIPCHK(launch_fold_leaf_subtree(cur, L, B, (const fp*)d_c0, fp_zero(), tw_inv, log_N, r - 1, next, (digest64*)digA, K, c->stream));
-                SHCHK(enqueue_forest_reduce(c, (const digest64*)digA, (digest64*)digB, (digest64*)digA, ilog2(half) - K, B, rec, gen));
+                HIPCHK(launch_fold_leaf_subtree(in, L, B, (const fp*)d_c0, fp_zero(), tw_inv, log_N, r - 1, next, (digest64*)digA, K, c->stream, d_abort));
+                SHCHK(enqueue_forest_reduce(c, (const digest64*)digA, (digest64*)digB, (digest64*)digA, ilog2(half) - K, B, rec, gen, d_abort));
             }
-            cur = next; L = half;
         }
         ++enq;
-        if (enq == R && stage_last) HIPCHK(launch_copy_to_host(cur, reinterpret_cast<fp*>(c->d_chain + lay.off_last), B * L, c->stream));
+        if (enq == R && stage_last) HIPCHK(launch_copy_to_host(R > 1 ? cw_of(R - 1) : d_cws, reinterpret_cast<fp*>(c->d_chain + lay.off_last), B * L_last, c->stream));
         return SH_OK;
     };
     SHCHK(enqueue_round());
@@ -223,9 +245,34 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
     const bool dbg = getenv("STARK_HIP_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_wait = 0, t_host = 0, t_enq = 0;
+    uint32_t retries = 0;
+    const uint32_t max_retries = 4 * R + 32;
     for (uint32_t r = 0; r < R; ++r) {
         const double t0 = now();
-        SHCHK(wait_seq(c, reinterpret_cast<const uint32_t*>(c->h_chain + lay.root_seq(r)), gen));
+        for (;;) {
+            const int32_t w = wait_seq(c, reinterpret_cast<const uint32_t*>(c->h_chain + lay.root_seq(r)), gen, r, timeout_s);
+            if (w == SH_OK) break;
+            if (w != WAIT_RETRY) return w;
+            // The wait kernel of round r (or of r+1, which then found root r published) ran out of spin before it saw the
+            // challenge: the host was slow (a long callback), or the kernel kept reading a stale copy of the record — seen
+            // when another host thread allocates or frees device memory while the kernel polls; a kernel launched afterwards
+            // reads the fresh value.  Everything behind it on the stream has returned at sight of the abort word, so no
+            // codeword or root of round >= r was written: drain, lower the flags, enqueue again from round r.
+            if (++retries > max_retries) return fail_gave_up(c, r, gen, retries - 1);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (__atomic_load_n(reinterpret_cast<const uint32_t*>(c->h_chain + lay.root_seq(r)), __ATOMIC_ACQUIRE) == gen) {
+                // root r did arrive: it was round r+1's wait that gave up; serve root r first, recover on the next wait
+                break;
+            }
+            for (int i = 0; i < 8; ++i) __atomic_store_n(h_abort + i, 0u, __ATOMIC_RELAXED);
+            c->batch_done_total = 0;
+            HIPCHK(hipMemsetAsync(c->d_flag + 16, 0, 4, c->stream));
+            HIPCHK(hipMemsetAsync(d_abort, 0, 4, c->stream));
+            enq = r;
+            SHCHK(enqueue_round());
+            if (enq < R) SHCHK(enqueue_round());
+            if (dbg) fprintf(stderr, "[stark_hip] round %u re-enqueued (%u so far)\n", r, retries);
+        }
         const double t1 = now();
         const bool want = r + 1 < R;
         SHCHK(fn(r, c->h_chain + lay.roots(r), want, alpha.data()));
@@ -247,6 +294,9 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
             fprintf(stderr, "[stark_hip] round %2u L=2^%-2u  wait root %6.1f us | transcript + c0 %5.1f us | enqueue ahead %5.1f us\n", r, ilog2(N >> r), t1 - t0, t2 - t1, t3 - t2);
         }
     }
+    c->chain_retries += retries;
+    const fp* cur = R > 1 ? cw_of(R - 1) : d_cws;
+    const size_t L = L_last;
     guard.armed = false;
     if (!stage_last) HIPCHK(hipMemcpyAsync(last_out, cur, last_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

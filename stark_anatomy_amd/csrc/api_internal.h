@@ -61,6 +61,7 @@ struct sh_ctx {
     uint8_t* h_chain = nullptr;                  // pinned, device-mapped: root / fold-constant records of a commit's rounds (api_fri.hip)
     uint8_t* d_chain = nullptr;                  // device view of h_chain
     size_t chain_bytes = 0;
+    uint64_t chain_retries = 0;                  // rounds enqueued a second time because a wait kernel ran out of spin
     uint32_t chain_gen = 0;                      // generation number of the last commit (the records' sequence value)
 };
 

@@ -22,7 +22,18 @@ struct alignas(16) digest64 {
 // h0 = IV0 ^ 0x01010040 (digest_length 64, key_length 0, fanout 1, depth 1)
 #define B2B_H0 (B2B_IV0 ^ 0x01010040ULL)
 
-__host__ __device__ __forceinline__ uint64_t b2b_rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+// 64-bit rotate right.  Device pass: two v_alignbit_b32 on the halves, spelled out — left to the funnel-shift matcher, a rotate
+// that is not fused with the xor feeding it comes out as v_lshrrev_b64 + v_lshlrev_b32 + v_or_b32.  n = 32 is a register swap.
+__host__ __device__ __forceinline__ uint64_t b2b_rotr(uint64_t x, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (n == 32) return ((uint64_t)lo << 32) | hi;
+    if (n < 32) return ((uint64_t)__builtin_amdgcn_alignbit(lo, hi, n) << 32) | __builtin_amdgcn_alignbit(hi, lo, n);
+    return ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, n - 32) << 32) | __builtin_amdgcn_alignbit(lo, hi, n - 32);
+#else
+    return (x >> n) | (x << (64 - n));
+#endif
+}
 
 #define B2B_G(a, b, c, d, x, y)                 \
     do {                                        \
@@ -32,16 +43,45 @@ __host__ __device__ __forceinline__ uint64_t b2b_rotr(uint64_t x, int n) { retur
         c = c + d;       b = b2b_rotr(b ^ c, 63); \
     } while (0)
 
-#define B2B_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
-    do {                                                   \
-        B2B_G(v0, v4, v8, v12, m[s0], m[s1]);              \
-        B2B_G(v1, v5, v9, v13, m[s2], m[s3]);              \
-        B2B_G(v2, v6, v10, v14, m[s4], m[s5]);             \
-        B2B_G(v3, v7, v11, v15, m[s6], m[s7]);             \
-        B2B_G(v0, v5, v10, v15, m[s8], m[s9]);             \
-        B2B_G(v1, v6, v11, v12, m[s10], m[s11]);           \
-        B2B_G(v2, v7, v8, v13, m[s12], m[s13]);            \
-        B2B_G(v3, v4, v9, v14, m[s14], m[s15]);            \
+// One half-round = four independent G's (the columns, or the diagonals).  On gfx950 the two-operand 32-bit ops of G (the
+// xors) issue at one wave-instruction per ~2.4 cycles per SIMD, every three-operand or 64-bit op (v_lshl_add_u64, v_alignbit)
+// at one per ~4.3, and a stream that alternates between the two classes loses 15-35 % to the switches
+// (profiles/r02_valu_opclass_microbench.txt, r02_mixorder_microbench.txt).  So the four G's advance in lock step, one
+// operation at a time across all four, with scheduling barriers between the op classes: runs of 8 xors between runs of
+// 8-16 adds/rotates instead of whatever interleaving the scheduler picks.  B2B_SB lets scalar and memory instructions
+// through, nothing else; on the host pass it is nothing.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(B2B_NO_GROUP)
+#define B2B_SB __builtin_amdgcn_sched_barrier(0x4 | 0x10 | 0x80)
+#else
+#define B2B_SB ((void)0)
+#endif
+#define B2B_G4(a0, b0, c0, d0, x0, y0, a1, b1, c1, d1, x1, y1, a2, b2, c2, d2, x2, y2, a3, b3, c3, d3, x3, y3)                       \
+    do {                                                                                                                             \
+        a0 = a0 + b0 + (x0); a1 = a1 + b1 + (x1); a2 = a2 + b2 + (x2); a3 = a3 + b3 + (x3);                                          \
+        B2B_SB;                                                                                                                      \
+        d0 = b2b_rotr(d0 ^ a0, 32); d1 = b2b_rotr(d1 ^ a1, 32); d2 = b2b_rotr(d2 ^ a2, 32); d3 = b2b_rotr(d3 ^ a3, 32);              \
+        B2B_SB;                                                                                                                      \
+        c0 = c0 + d0; c1 = c1 + d1; c2 = c2 + d2; c3 = c3 + d3;                                                                      \
+        B2B_SB;                                                                                                                      \
+        b0 ^= c0; b1 ^= c1; b2 ^= c2; b3 ^= c3;                                                                                      \
+        B2B_SB;                                                                                                                      \
+        b0 = b2b_rotr(b0, 24); b1 = b2b_rotr(b1, 24); b2 = b2b_rotr(b2, 24); b3 = b2b_rotr(b3, 24);                                  \
+        a0 = a0 + b0 + (y0); a1 = a1 + b1 + (y1); a2 = a2 + b2 + (y2); a3 = a3 + b3 + (y3);                                          \
+        B2B_SB;                                                                                                                      \
+        d0 ^= a0; d1 ^= a1; d2 ^= a2; d3 ^= a3;                                                                                      \
+        B2B_SB;                                                                                                                      \
+        d0 = b2b_rotr(d0, 16); d1 = b2b_rotr(d1, 16); d2 = b2b_rotr(d2, 16); d3 = b2b_rotr(d3, 16);                                  \
+        c0 = c0 + d0; c1 = c1 + d1; c2 = c2 + d2; c3 = c3 + d3;                                                                      \
+        B2B_SB;                                                                                                                      \
+        b0 ^= c0; b1 ^= c1; b2 ^= c2; b3 ^= c3;                                                                                      \
+        B2B_SB;                                                                                                                      \
+        b0 = b2b_rotr(b0, 63); b1 = b2b_rotr(b1, 63); b2 = b2b_rotr(b2, 63); b3 = b2b_rotr(b3, 63);                                  \
+    } while (0)
+
+#define B2B_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                                             \
+    do {                                                                                                                             \
+        B2B_G4(v0, v4, v8, v12, m[s0], m[s1], v1, v5, v9, v13, m[s2], m[s3], v2, v6, v10, v14, m[s4], m[s5], v3, v7, v11, v15, m[s6], m[s7]);     \
+        B2B_G4(v0, v5, v10, v15, m[s8], m[s9], v1, v6, v11, v12, m[s10], m[s11], v2, v7, v8, v13, m[s12], m[s13], v3, v4, v9, v14, m[s14], m[s15]); \
     } while (0)
 
 // One final-block compression from the initial chaining value, `t` message bytes.  m[] is indexed

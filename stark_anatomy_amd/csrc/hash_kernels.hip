@@ -159,7 +159,9 @@ __device__ __forceinline__ fp load_tw(const fp* __restrict__ tw, uint32_t log_n,
 // constant c0 = alpha/(2*offset) comes from `c0_arr[b]` (device, Montgomery form) or, when null, `c0_single`.
 __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const fp* __restrict__ cw, uint32_t log_half, const fp* __restrict__ c0_arr,
                                                            fp c0_single, const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
-                                                           fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out, uint32_t K) {
+                                                           fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out, uint32_t K,
+                                                           const uint32_t* __restrict__ d_abort) {
+    if (d_abort && __hip_atomic_load(d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     const size_t j0 = i << K, half = (size_t)1 << log_half;
@@ -186,8 +188,10 @@ __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const 
 #define STAGE_WAVE_ELEMS (64 * STAGE_ROW)
 __global__ __launch_bounds__(256, 2) void k_fold_leaf_subtree_staged(const fp* __restrict__ cw, uint32_t log_half, const fp* __restrict__ c0_arr, fp c0_single,
                                                                      const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
-                                                                     fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out) {
+                                                                     fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out,
+                                                                     const uint32_t* __restrict__ d_abort) {
     __shared__ fp s_lo[4 * STAGE_WAVE_ELEMS], s_hi[4 * STAGE_WAVE_ELEMS];
+    if (d_abort && __hip_atomic_load(d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // n_out is a multiple of 64: whole waves are in or out
     if (i >= n_out) return;
@@ -283,7 +287,7 @@ hipError_t launch_fri_fold(const fp* lo, const fp* hi, size_t half, fp c0_mont, 
     return hipGetLastError();
 }
 hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* c0_arr, fp c0_single, const fp* tw_inv, uint32_t log_n_table,
-                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s) {
+                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s, const uint32_t* d_abort) {
     const size_t half = L / 2;
     if (!half || (half & (half - 1)) || !B || K > SUBTREE_KMAX || (half >> K) == 0) return hipErrorInvalidValue;
     uint32_t log_half = 0;
@@ -292,11 +296,11 @@ hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* 
     static const bool no_stage = getenv("STARK_NO_STAGE") != nullptr;
     if (K == 3 && (n_out & 255) == 0 && log_half >= 9 && !no_stage) {          // whole 256-lane workgroups, waves inside one codeword
         hipLaunchKernelGGL(k_fold_leaf_subtree_staged, dim3((unsigned)(n_out >> 8)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
-                           log_n_table, tw_shift, out, digests, n_out);
+                           log_n_table, tw_shift, out, digests, n_out, d_abort);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_fold_leaf_subtree, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
-                       log_n_table, tw_shift, out, digests, n_out, K);
+                       log_n_table, tw_shift, out, digests, n_out, K, d_abort);
     return hipGetLastError();
 }
 

@@ -48,7 +48,9 @@ hipError_t launch_merkle_tail(const digest64* in, digest64* root, size_t n_in, h
 // levels in LDS.  With `mailbox` (single-workgroup launch only) the root + `seq` also go to pinned host memory.
 #define QUAD_MAX_LOG_CHUNK 9
 hipError_t launch_quad_reduce(const digest64* in, digest64* out, size_t n_in, uint32_t log_chunk, uint64_t* mailbox, uint32_t seq, hipStream_t s,
-                              uint32_t* counter = nullptr, uint32_t target = 0);
+                              uint32_t* counter = nullptr, uint32_t target = 0, const uint32_t* d_abort = nullptr);
+// d_abort (here and below): device word that a wait kernel raises when it abandons its round; a kernel given it returns at once
+// when it is set, so an abandoned round neither publishes a root nor overwrites a codeword that the retry still needs.
 
 // ---- hash_kernels.hip (FRI round) ----
 // generic split-and-fold (any omega): out[i] = (a+b)/2 + c0·omega^-i·(a-b),  c0 = alpha/(2·offset)
@@ -58,7 +60,7 @@ hipError_t launch_fri_fold(const fp* lo, const fp* hi, size_t half, fp c0_mont, 
 // subtree digests of the folded codewords.  c0 = alpha/(2*offset) in Montgomery form: per codeword from the device
 // array `c0_arr`, or `c0_single` when c0_arr is null.
 hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* c0_arr, fp c0_single, const fp* tw_inv, uint32_t log_n_table,
-                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s);
+                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s, const uint32_t* d_abort = nullptr);
 
 // ---- round_kernels.hip (the commit's serial chain) ----
 // one workgroup: wait until the pinned host word *h_seq carries `gen` (bit 31 = abort), then copy the B fold constants
@@ -66,14 +68,14 @@ hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* 
 hipError_t launch_wait_c0(const uint32_t* h_seq, uint32_t gen, const fp* h_c0, fp* d_c0, size_t B, uint32_t* d_abort, uint32_t* h_abort, uint64_t timeout_ticks,
                           hipStream_t s);
 // B digests that are already roots -> pinned host record, then the sequence word
-hipError_t launch_publish_digests(const digest64* in, size_t B, uint64_t* h_roots, uint32_t* h_seq, uint32_t seq, hipStream_t s);
+hipError_t launch_publish_digests(const digest64* in, size_t B, uint64_t* h_roots, uint32_t* h_seq, uint32_t seq, hipStream_t s, const uint32_t* d_abort = nullptr);
 // n elements -> device-mapped pinned host memory (the last codeword of a commit)
 hipError_t launch_copy_to_host(const fp* src, fp* h_dst, size_t n, hipStream_t s);
 // One small FRI round (B·2^log_half <= 2^15 outputs) in one launch: [wait for the challenge,] fold, leaf-hash and the bottom
 // min(7, log_half) tree levels.  Trees that end inside a workgroup publish their roots to the host record (rec_*; `counter` /
 // `target` as launch_quad_reduce when there is more than one workgroup), the others leave 128-leaf sub-roots in sub_out.
 // fold == false: round 0, `cw` holds the leaves (B trees of 2^log_half) and nothing is waited for.
-// Waiting: h_seq != null (only B == 1; keep the grid small: lane 0 of every workgroup polls host memory) -> the kernel polls the c0 record itself; else c0 = d_c0[b], filled by a
+// Waiting: h_seq != null (only B == 1 and a single workgroup) -> the kernel polls the c0 record itself; else c0 = d_c0[b], filled by a
 // launch_wait_c0 in front of this launch.
 hipError_t launch_round_wg(bool fold, const fp* cw, fp* out, uint32_t log_half, size_t B, const uint32_t* h_seq, uint32_t gen, const fp* h_c0, const fp* d_c0, uint32_t* d_abort,
                            uint32_t* h_abort, uint64_t timeout_ticks, const fp* tw_inv, uint32_t log_n_table, uint32_t tw_shift, digest64* sub_out,

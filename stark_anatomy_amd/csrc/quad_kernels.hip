@@ -25,8 +25,10 @@
 // pinned host memory, every workgroup stores its root there with system-scope stores, bumps `counter`, and the
 // workgroup that brings it to `target` publishes `seq`.  (`counter` only ever grows; the host passes the running total.)
 __global__ __launch_bounds__(QR_THREADS) void k_quad_reduce(const digest64* __restrict__ in, digest64* __restrict__ out, uint32_t log_chunk,
-                                                            uint64_t* __restrict__ mailbox, uint32_t seq, uint32_t* __restrict__ counter, uint32_t target) {
+                                                            uint64_t* __restrict__ mailbox, uint32_t seq, uint32_t* __restrict__ counter, uint32_t target,
+                                                            const uint32_t* __restrict__ d_abort) {
     __shared__ __align__(16) uint64_t sm[QR_LDS_U64];
+    if (d_abort && __hip_atomic_load(d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // the round was abandoned upstream: publish nothing
     const uint32_t tid = threadIdx.x;
     const uint32_t chunk = 1u << log_chunk;
     const QuadLane L = quad_lane_init(tid & 3);
@@ -62,11 +64,11 @@ __global__ __launch_bounds__(QR_THREADS) void k_quad_reduce(const digest64* __re
 }
 
 hipError_t launch_quad_reduce(const digest64* in, digest64* out, size_t n_in, uint32_t log_chunk, uint64_t* mailbox, uint32_t seq, hipStream_t s,
-                              uint32_t* counter, uint32_t target) {
+                              uint32_t* counter, uint32_t target, const uint32_t* d_abort) {
     if (log_chunk < 1 || log_chunk > 9 || n_in == 0 || (n_in & ((((size_t)1) << log_chunk) - 1))) return hipErrorInvalidValue;
     const size_t blocks = n_in >> log_chunk;
     if (mailbox && !counter && blocks != 1) return hipErrorInvalidValue;
     if (counter && !mailbox) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_quad_reduce, dim3((unsigned)blocks), dim3(QR_THREADS), 0, s, in, out, log_chunk, mailbox, seq, counter, target);
+    hipLaunchKernelGGL(k_quad_reduce, dim3((unsigned)blocks), dim3(QR_THREADS), 0, s, in, out, log_chunk, mailbox, seq, counter, target, d_abort);
     return hipGetLastError();
 }

@@ -421,6 +421,78 @@ def test_two_contexts_in_two_threads():
     assert not errors, errors
 
 
+def test_commit_recovers_when_wait_kernels_run_out_of_spin(monkeypatch):
+    """stark_hip.h (commit driver): the GPU-side wait for a challenge is a bounded spin and its expiry is a re-launch, not
+    an error.  With a 1 us budget and a transcript slower than that (a Python callback; 512 transcripts per round) rounds
+    are abandoned and enqueued again; roots, last codeword and transcript must still be the oracle's — single codeword
+    (wide rounds and the fused small rounds) and a batch (the shared completion counter is reset on the way)."""
+    monkeypatch.setenv("STARK_HIP_CHAIN_SPIN_US", "1")
+    c = sa.Context(0)
+    try:
+        for seed, log_n in ((21, 18), (22, 10)):
+            cw = co.splitmix_elems(seed, 1 << log_n)
+            r, alphas, l, _ = co.fri_commit(cw, 4, 17, G)
+            before = c.chain_retries
+            for _ in range(2):
+                pps, seen = po.ProofStream(), []
+
+                def cb(rnd, root, want):
+                    pps.push(po.item_root(root))
+                    if want:
+                        a = po.sample(pps.prover_fiat_shamir()); seen.append(a); return a
+                roots, last = sa.Fri(G, None, 1 << log_n, 4, 17, ctx=c).commit_with_callback(cw, cb)
+                assert [h.as_bytes() for h in roots] == r and np.array_equal(last, l) and seen == alphas
+            assert c.chain_retries > before, "the retry path did not run"
+        B, log_n = 512, 9
+        cws = np.stack([co.splitmix_elems(300 + b, 1 << log_n) for b in range(B)])
+        before = c.chain_retries
+        streams = [sa.ProofStream() for _ in range(B)]
+        roots, last = sa.Fri(G, None, 1 << log_n, 4, 17, ctx=c).commit_batch(cws, streams)
+        assert c.chain_retries > before, "the retry path did not run for the batch"
+        for b in (0, 1, 255, B - 1):
+            r, _, l, ps = co.fri_commit(cws[b], 4, 17, G)
+            assert [h.as_bytes() for h in roots[b]] == r and (last[b] == l).all() and streams[b].serialize() == ps.serialize()
+    finally:
+        c.close()
+
+
+def test_commit_while_another_thread_allocates_and_frees():
+    """A kernel that polls pinned host memory can keep reading a stale value for as long as it runs when another host
+    thread allocates or frees device memory meanwhile (measured on this stack).  The commit driver must ride
+    that out through its bounded spin + re-launch: commits in one thread, hipMalloc/hipFree churn in another."""
+    import threading
+    log_n = 15
+    cw = co.splitmix_elems(31, 1 << log_n)
+    r, _, l, ps_exp = co.fri_commit(cw, 4, 17, G)
+    ser = ps_exp.serialize()
+    stop = threading.Event()
+    errors = []
+
+    def churn():
+        try:
+            c2 = sa.Context(0)
+            while not stop.is_set():
+                bufs = [c2.alloc(1 << 20) for _ in range(4)]
+                for b in bufs:
+                    b.free()
+            c2.close()
+        except Exception as e:
+            errors.append(e)
+    t = threading.Thread(target=churn)
+    t.start()
+    c = sa.Context(0)
+    try:
+        for _ in range(40):
+            ps = sa.ProofStream()
+            roots, last = sa.Fri(G, None, 1 << log_n, 4, 17, ctx=c).commit(cw, ps)
+            assert [h.as_bytes() for h in roots] == r and np.array_equal(last, l) and ps.serialize() == ser
+    finally:
+        stop.set()
+        t.join()
+        c.close()
+    assert not errors, errors
+
+
 def test_c5_full_size_2_24_vs_oracle(ctx):
     """BASELINE config 5's data at full size, directly against the oracle (no sampling): n = 2^22 coefficients (seed 5)
     -> coset LDE to N = 2^24 -> full FRI commit; codeword, every root, the last codeword and the serialized proof

@@ -22,6 +22,17 @@
 #define ADD3_I(i) "v_add3_u32 %" #i ", %" #i ", %8, %8\n"
 #define ADDCOP_I(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\nv_addc_co_u32 %" #i ", vcc, %" #i ", %8, vcc\n"
 #define XAD_I(i) "v_xad_u32 %" #i ", %" #i ", %8, %8\n"
+// round 2: separate ENCODING size (VOP2 = 4 bytes, VOP3 = 8 bytes) from OP CLASS: the same two-operand ops forced into the
+// 8-byte encoding, a three-operand float op the guide prices at full rate, and the other byte/bit permutes
+#define XOR64E_I(i) "v_xor_b32_e64 %" #i ", %" #i ", %8\n"
+#define ADD64E_I(i) "v_add_u32_e64 %" #i ", %" #i ", %8\n"
+#define FMA_I(i) "v_fma_f32 %" #i ", %" #i ", %8, %8\n"
+#define VPERM_I(i) "v_perm_b32 %" #i ", %" #i ", %8, %8\n"
+#define BFI_I(i) "v_bfi_b32 %" #i ", %" #i ", %8, %8\n"
+#define XOR3_I(i) "v_or3_b32 %" #i ", %" #i ", %8, %8\n"
+#define LSHLOR_I(i) "v_lshl_or_b32 %" #i ", %" #i ", 3, %8\n"
+#define FMAC_I(i) "v_fmac_f32 %" #i ", %8, %8\n"
+#define LSHR_I(i) "v_lshrrev_b32 %" #i ", 7, %" #i "\n"
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k32(uint32_t* out, int iters, uint32_t seed) {
@@ -36,6 +47,15 @@ __global__ __launch_bounds__(256) void k32(uint32_t* out, int iters, uint32_t se
         if (KIND == 5) asm volatile(BLOCK(MULHI_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
         if (KIND == 6) asm volatile(BLOCK(ADD3_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
         if (KIND == 7) asm volatile(BLOCK(XAD_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 9) asm volatile(BLOCK(XOR64E_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 10) asm volatile(BLOCK(ADD64E_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 11) asm volatile(BLOCK(FMA_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 12) asm volatile(BLOCK(VPERM_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 13) asm volatile(BLOCK(BFI_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 14) asm volatile(BLOCK(XOR3_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 15) asm volatile(BLOCK(LSHLOR_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 16) asm volatile(BLOCK(FMAC_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 17) asm volatile(BLOCK(LSHR_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
         if (KIND == 8) asm volatile(BLOCK(ADDCOP_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
@@ -81,18 +101,20 @@ int main() {
     const int iters = 4000;
     void* buf;
     CHK(hipMalloc(&buf, (size_t)256 * 8 * 4 * 256 * 8));
-    const char* n32[] = {"v_xor_b32", "v_add_u32", "v_alignbit_b32", "v_alignbyte_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_add3_u32", "v_xad_u32", "add_co+addc (x2 instr)"};
+    const char* n32[] = {"v_xor_b32", "v_add_u32", "v_alignbit_b32", "v_alignbyte_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_add3_u32", "v_xad_u32", "add_co+addc (x2 instr)",
+                         "v_xor_b32_e64 (VOP3 enc)", "v_add_u32_e64 (VOP3 enc)", "v_fma_f32 (VOP3)", "v_perm_b32", "v_bfi_b32", "v_or3_b32", "v_lshl_or_b32", "v_fmac_f32 (VOP2)", "v_lshrrev_b32 (VOP2)"};
     const char* n64[] = {"v_lshl_add_u64", "v_mad_u64_u32", "v_lshrrev_b64", "v_lshlrev_b64", "v_mov_b64"};
-    for (int wps = 1; wps <= 8; wps *= 2) if (wps != 2) {                // waves per SIMD
+    for (int wps = 4; wps <= 8; wps *= 2) {                // waves per SIMD
         const int blocks = 256 * wps;                      // 256 CUs x (wps*4 waves = wps blocks of 256 threads)
         const double lane_ops = (double)blocks * 256 * iters * 64;
         printf("--- %d wave(s) per SIMD (%d blocks of 256) ---\n", wps, blocks);
         double ms;
 #define RUN32(K) ms = time_ms([&] { hipLaunchKernelGGL(k32<K>, dim3(blocks), dim3(256), 0, 0, (uint32_t*)buf, iters, 7u); }); \
-        printf("%-16s %8.3f ms  %8.2f T lane-ops/s\n", n32[K], ms, lane_ops / ms / 1e9);
+        printf("%-26s %8.3f ms  %8.2f T lane-ops/s  %5.2f cycles/instr/SIMD @2.4GHz\n", n32[K], ms, lane_ops / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)wps * iters * 64));
         RUN32(0) RUN32(1) RUN32(2) RUN32(3) RUN32(4) RUN32(5) RUN32(6) RUN32(7) RUN32(8)
+        RUN32(9) RUN32(10) RUN32(11) RUN32(12) RUN32(13) RUN32(14) RUN32(15) RUN32(16) RUN32(17)
 #define RUN64(K) ms = time_ms([&] { hipLaunchKernelGGL(k64<K>, dim3(blocks), dim3(256), 0, 0, (uint64_t*)buf, iters, 7u); }); \
-        printf("%-16s %8.3f ms  %8.2f T lane-ops/s\n", n64[K], ms, lane_ops / ms / 1e9);
+        printf("%-26s %8.3f ms  %8.2f T lane-ops/s  %5.2f cycles/instr/SIMD @2.4GHz\n", n64[K], ms, lane_ops / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)wps * iters * 64));
         RUN64(0) RUN64(1) RUN64(2) RUN64(3) RUN64(4)
     }
     CHK(hipDeviceSynchronize());
