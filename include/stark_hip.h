@@ -64,9 +64,10 @@ int32_t sh_dev_download(sh_ctx* ctx, void* host, const void* dptr, size_t bytes)
 
 /* ---------------- field, batched (field.rs) ----------------
  * out[i] = a[i] (+,-,*) b[i]  — `impl Add/Sub/Mul for FieldElement`, field.rs:57-95.
- * sh_fp_div: out[i] = a[i] / b[i] — field.rs:97-114; SH_EDIVZERO if any b[i] == 0 (outputs then
- * unspecified).  sh_fp_inv: out[i] = 1 / a[i].  Inputs must be canonical (as `FieldElement::new`
- * guarantees, field.rs:30-35); sh_fp_new reduces arbitrary u128 values first. */
+ * sh_fp_div: out[i] = a[i] / b[i] — field.rs:97-114; SH_EDIVZERO if any b[i] == 0 (field.rs:101-103: out[i] = 0 at those
+ * positions, every other quotient is still written).  sh_fp_inv: out[i] = 1 / a[i], same rule.  Division and inversion
+ * are batched by Montgomery's trick: one field inversion per 2048 elements, 3-4 multiplies per element.
+ * Inputs must be canonical (as `FieldElement::new` guarantees, field.rs:30-35); sh_fp_new reduces arbitrary u128 values first. */
 int32_t sh_fp_new(sh_ctx* ctx, const uint64_t* x, uint64_t* out, size_t n);
 int32_t sh_fp_add(sh_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int32_t sh_fp_sub(sh_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
@@ -100,6 +101,25 @@ int32_t sh_coset_lde(sh_ctx* ctx, const uint64_t* coeffs, uint32_t log_n, uint32
                      const uint64_t offset[2], uint64_t* out);
 int32_t sh_dev_coset_lde(sh_ctx* ctx, const uint64_t* d_coeffs, uint32_t log_n, uint32_t log_expansion,
                          const uint64_t offset[2], uint64_t* d_out);
+
+/* ---------------- polynomial layer ----------------
+ * NO COUNTERPART IN THE REFERENCE CRATE (it has no polynomial type): these are the operations a STARK prover
+ * needs next to the FRI commit, defined as in DESIGN.md §10 and pinned by the oracle's schoolbook restatement.
+ * A polynomial is its coefficient array, lowest degree first, at least one coefficient, no trimming.
+ * sh_poly_mul: out[0 .. na+nb-1) = a · b, through the NTT (na + nb - 1 <= 2^SH_MAX_LOG_N). */
+int32_t sh_poly_mul(sh_ctx* ctx, const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out);
+int32_t sh_dev_poly_mul(sh_ctx* ctx, const uint64_t* d_a, size_t na, const uint64_t* d_b, size_t nb, uint64_t* d_out);
+/* Quotient by the zerofier Z(X) = X^n - c, n = 2^log_n, of evaluations on the coset {offset·w_N^i}, N = 2^log_N >= n:
+ * out[i] = cw[i] / Z(offset·w_N^i).  Z takes only N/n distinct values there: they are inverted in one batch.
+ * SH_EDIVZERO if the coset meets a root of Z (field.rs:101-103). */
+int32_t sh_coset_zerofier_div(sh_ctx* ctx, const uint64_t* cw, uint32_t log_N, uint32_t log_n, const uint64_t offset[2],
+                              const uint64_t c[2], uint64_t* out);
+int32_t sh_dev_coset_zerofier_div(sh_ctx* ctx, const uint64_t* d_cw, uint32_t log_N, uint32_t log_n, const uint64_t offset[2],
+                                  const uint64_t c[2], uint64_t* d_out);
+/* Coefficient form: f = q · (X^n - c) + r with deg r < n, any n >= 1.  q gets nf - n coefficients (none, and q may be NULL,
+ * if nf <= n), r gets n (zero-padded).  Parallel over the n residue classes of the exponent, nf/n steps deep. */
+int32_t sh_poly_divmod_zerofier(sh_ctx* ctx, const uint64_t* f, size_t nf, size_t n, const uint64_t c[2], uint64_t* q, uint64_t* r);
+int32_t sh_dev_poly_divmod_zerofier(sh_ctx* ctx, const uint64_t* d_f, size_t nf, size_t n, const uint64_t c[2], uint64_t* d_q, uint64_t* d_r);
 
 /* ---------------- Merkle (merkle.rs) ----------------
  * sh_merkle_commit == `MerkleTree::commit(&[MerkleHash]).root`, merkle.rs:35-68: Blake2b-512 over

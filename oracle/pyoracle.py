@@ -355,6 +355,55 @@ def fri_verify(ps, N, expansion, num_colinearity_tests, offset):           # G12
     return True, ""
 
 
+# ------------------------------------------------------------------ polynomial layer
+# The reference crate has no polynomial code; these are the textbook definitions (schoolbook product, long division,
+# pointwise quotient), deliberately NOT the NTT / Montgomery's-trick algorithms the GPU uses.  Coefficients lowest degree first.
+def poly_mul(a, b):
+    out = [0] * (len(a) + len(b) - 1)
+    for i, x in enumerate(a):
+        if x:
+            for j, y in enumerate(b):
+                out[i + j] = (out[i + j] + x * y) % P
+    return out
+
+
+def poly_eval(f, x):
+    acc = 0
+    for c in reversed(f):
+        acc = (acc * x + c) % P
+    return acc
+
+
+def poly_divmod(f, d):
+    """long division by a polynomial with non-zero leading coefficient: (q, r), len(q) = max(len(f)-deg d, 0), len(r) = deg d"""
+    f, dd = list(f), len(d) - 1
+    lead_inv = fp_inv(d[-1])
+    q = [0] * max(len(f) - dd, 0)
+    for k in range(len(f) - 1, dd - 1, -1):
+        coef = fp_mul(f[k], lead_inv)
+        q[k - dd] = coef
+        for j, y in enumerate(d):
+            f[k - dd + j] = fp_sub(f[k - dd + j], fp_mul(coef, y))
+    r = (f[:dd] + [0] * dd)[:dd]
+    return q, r
+
+
+def poly_divmod_zerofier(f, n, c):
+    """f = q·(X^n − c) + r by generic long division"""
+    return poly_divmod(f, [fp_sub(0, c)] + [0] * (n - 1) + [1])
+
+
+def coset_zerofier_div(cw, log_n, c, offset):
+    """cw[i] / ((offset·w_N^i)^n − c), n = 2^log_n; ZeroDivisionError where the coset meets a root (field.rs:101-103)"""
+    N = len(cw)
+    w = root_of_unity(N.bit_length() - 1)
+    out, x = [], offset % P
+    for v in cw:
+        out.append(fp_div(v, fp_sub(pow(x, 1 << log_n, P), c)))
+        x = x * w % P
+    return out
+
+
 def splitmix_elems(seed, n):                                     # SURVEY §8d
     s = seed & MASK64; out = []
     for _ in range(n):

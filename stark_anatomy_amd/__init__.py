@@ -6,6 +6,7 @@ crate (greged93/stark-anatomy), behind the crate's own API surface:
     merkle       MerkleHash, MerkleTree.commit / open / verify
     proof_stream ProofStream.push / pull / serialize / deserialize / *_fiat_shamir
     ntt, fri     NTT / INTT / coset LDE, split-and-fold, Fri.commit  (the layer the reference lacks)
+    poly         products through the NTT, zerofier quotients, batched inversion
 
 Everything computes in hand-written HIP kernels through libstark_hip.so (C ABI: include/stark_hip.h).
 There is no CPU fallback: importing this package without the built library raises ImportError.
@@ -19,12 +20,13 @@ from .field import GENERATOR, ONE, PRIME, ZERO, FieldElement, FieldVector, gener
 from .fri import Fri, fold, sample, sample_indices
 from .merkle import MerkleHash, MerkleTree, commit_elems, hash_leaves
 from .ntt import coset_lde, dev_coset_lde, dev_ntt, intt, ntt
+from .poly import coset_zerofier_div, poly_divmod_zerofier, poly_mul
 from .proof_stream import OutOfBoundsReadIndexError, ProofItem, ProofStream, ProofStreamError, SerializationError
 
 __all__ = [
     "StarkHipError", "Context", "DeviceBuffer", "default_context", "elems_to_array", "array_to_ints",
     "PRIME", "GENERATOR", "ZERO", "ONE", "FieldElement", "FieldVector", "generator", "root_of_unity",
     "Fri", "fold", "sample", "MerkleHash", "MerkleTree", "commit_elems", "hash_leaves",
-    "ntt", "intt", "coset_lde", "dev_ntt", "dev_coset_lde",
+    "ntt", "intt", "coset_lde", "dev_ntt", "dev_coset_lde", "poly_mul", "coset_zerofier_div", "poly_divmod_zerofier",
     "ProofStream", "ProofItem", "ProofStreamError", "OutOfBoundsReadIndexError", "SerializationError",
 ]

@@ -169,14 +169,15 @@ static int32_t host_fp_op(sh_ctx* c, int op, const uint64_t* a, const uint64_t* 
         SHCHK(ensure_scratch(c, SCR_IO_B, n * 16, &db));
         HIPCHK(hipMemcpyAsync(db, b, n * 16, hipMemcpyHostToDevice, c->stream));
     }
-    SHCHK(dev_fp_op(c, op, (const uint64_t*)da, (const uint64_t*)db, (uint64_t*)dout, n));
-    HIPCHK(hipMemcpyAsync(out, dout, n * 16, hipMemcpyDeviceToHost, c->stream));
+    const int32_t rc = dev_fp_op(c, op, (const uint64_t*)da, (const uint64_t*)db, (uint64_t*)dout, n);
+    if (rc != SH_OK && rc != SH_EDIVZERO) return rc;
+    HIPCHK(hipMemcpyAsync(out, dout, n * 16, hipMemcpyDeviceToHost, c->stream));   // a zero divisor: 0 there, every other result is valid
     HIPCHK(hipStreamSynchronize(c->stream));
-    return SH_OK;
+    return rc;
 }
 
 // ------------------------------------------------------------------ NTT / LDE
-static int32_t dev_ntt(sh_ctx* c, fp* d_data, uint32_t log_n, bool inverse, size_t batch = 1) {
+int32_t dev_ntt(sh_ctx* c, fp* d_data, uint32_t log_n, bool inverse, size_t batch) {
     if (log_n > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "ntt: log_n %u > %d", log_n, SH_MAX_LOG_N);
     if (batch == 0) return SH_OK;
     if (batch > ((size_t)1 << (SH_MAX_LOG_N + 2 - log_n))) return sh_failf(SH_EINVAL, "ntt: batch %zu x 2^%u exceeds 2^%d elements", batch, log_n, SH_MAX_LOG_N + 2);

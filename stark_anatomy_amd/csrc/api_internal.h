@@ -36,9 +36,9 @@
     } while (0)
 
 // ------------------------------------------------------------------ context
-#define NUM_SCRATCH 12
+#define NUM_SCRATCH 14
 enum { SCR_IO_A = 0, SCR_IO_B = 1, SCR_IO_C = 2, SCR_WORK = 3, SCR_DIG_A = 4, SCR_DIG_B = 5, SCR_ROOTS = 6, SCR_C0 = 7,
-       SCR_ARENA = 8, SCR_LEVELS = 9, SCR_IDX = 10, SCR_PATHS = 11 };
+       SCR_ARENA = 8, SCR_LEVELS = 9, SCR_IDX = 10, SCR_PATHS = 11, SCR_POLY_A = 12, SCR_POLY_B = 13 };
 struct sh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -84,6 +84,7 @@ static inline fp host_root_of_unity(uint32_t log_n) {
 // api.hip
 int32_t ensure_scratch(sh_ctx* c, int slot, size_t bytes, void** out);
 int32_t get_twiddles(sh_ctx* c, uint32_t log_n, bool inverse, const fp** out);
+int32_t dev_ntt(sh_ctx* c, fp* d_data, uint32_t log_n, bool inverse, size_t batch = 1);   // natural order in and out, on the context's stream
 // api_merkle.hip
 int32_t reduce_digests(sh_ctx* c, const digest64* cur, size_t count);
 uint32_t leaf_subtree_k(uint32_t log_L);

@@ -126,3 +126,24 @@ FP_HD fp fp_pow(fp a, fp_u128 e) {
 }
 // a^-1 = a^(p-2): the unique inverse in [1,p) that field.rs:109-110 derives from ext-Euclid. a != 0.
 FP_HD fp fp_inv(fp a) { return fp_pow(a, fp_prime_u128() - 2); }
+// Inverse inside the Montgomery domain: am = a·R -> a^-1·R, am != 0.  p − 2 = 406·2^119 + (2^119 − 1) is 110010110b
+// followed by 119 ones, so the ladder is walked from the top with a 7-bit window over the run of ones:
+// 133 squarings + 27 multiplies instead of the 128 + 125 of the plain ladder.
+FP_HD fp mont_inv(fp am) {
+    fp w = am;                                    // am^(2^k − 1), k = 1..7
+#pragma unroll 1
+    for (int k = 1; k < 7; ++k) w = mont_mul(mont_mul(w, w), am);
+    fp r = am;                                    // am^406: bits after the leading one of 110010110b
+#pragma unroll 1
+    for (int k = 7; k >= 0; --k) {
+        r = mont_mul(r, r);
+        if ((406u >> k) & 1u) r = mont_mul(r, am);
+    }
+#pragma unroll 1
+    for (int g = 0; g < 17; ++g) {                // 17 x 7 = 119 ones
+#pragma unroll 1
+        for (int k = 0; k < 7; ++k) r = mont_mul(r, r);
+        r = mont_mul(r, w);
+    }
+    return r;
+}

@@ -7,9 +7,18 @@
 #include "fp128.cuh"
 
 // ---- field_kernels.hip ----
-enum { FPOP_ADD = 0, FPOP_SUB = 1, FPOP_MUL = 2, FPOP_DIV = 3, FPOP_INV = 4, FPOP_NEW = 5 };
-// out[i] = a[i] op b[i]; *d_flag is set to 1 if a zero divisor is met (FPOP_DIV / FPOP_INV).
+enum { FPOP_ADD = 0, FPOP_SUB = 1, FPOP_MUL = 2, FPOP_DIV = 3, FPOP_INV = 4, FPOP_NEW = 5, FPOP_INV_MONT = 6 };
+// out[i] = a[i] op b[i]; *d_flag is set to 1 if a zero divisor is met (FPOP_DIV / FPOP_INV / FPOP_INV_MONT: batched
+// inversion, one field inversion per 2048 elements).  FPOP_INV_MONT: out = 2^128 / a, the factor that makes
+// mont_mul(x, out) = x / a.
 hipError_t launch_fp_binop(int op, const fp* a, const fp* b, fp* out, size_t n, uint32_t* d_flag, hipStream_t s);
+// ---- poly_kernels.hip ----
+// z[k] = start · w^k − c, k < count   (values of the zerofier X^n − c over one period of a coset; w_mont = w·2^128)
+hipError_t launch_zerofier_values(fp* z, size_t count, fp start, fp w_mont, fp c, hipStream_t s);
+// out[i] = mont_mul(in[i], factor[i & mask])
+hipError_t launch_mul_periodic(const fp* in, const fp* factor, size_t mask, fp* out, size_t n, hipStream_t s);
+// f = q · (X^n − c) + r: q (nf − n coefficients, none if nf <= n) and r (n coefficients); c_mont = c·2^128
+hipError_t launch_divmod_zerofier(const fp* f, size_t nf, size_t n, fp c_mont, fp* q, fp* r, hipStream_t s);
 
 // ---- ntt_kernels.hip ----
 #define NTT_MAX_PASSES 4

@@ -147,6 +147,52 @@ def main():
     dump("c2_lde_merkle.json", {"log_n": 16, "log_expansion": 2, "seed": 2, "offset": str(G), "lde_sha256": elems_digest(y),
                                 "ntt_sha256": elems_digest(po.ntt(c)), "merkle_root": po.merkle_commit_elems(y).hex()})
 
+    poly_goldens()
+
+
+def poly_goldens():
+    """---- polynomial layer: schoolbook product, long division, pointwise zerofier quotient ----
+    (also callable alone: python tests/golden/gen_golden.py poly)"""
+    EDGE = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, (1 << 64) - 1, 1 << 64, 1 << 119, (1 << 127) - 1]
+    mul = []
+    for seed, na, nb in ((40, 1, 1), (41, 3, 5), (42, 64, 64), (43, 100, 29), (44, 257, 255)):
+        a, b = po.splitmix_elems(seed, na), po.splitmix_elems(seed + 100, nb)
+        prod = po.poly_mul(a, b)
+        e = {"seed_a": seed, "na": na, "seed_b": seed + 100, "nb": nb, "sha256": elems_digest(prod)}
+        if len(prod) <= 8:
+            e["a"], e["b"], e["product"] = [str(v) for v in a], [str(v) for v in b], [str(v) for v in prod]
+        mul.append(e)
+    a, b = EDGE[:7], EDGE[3:]
+    mul.append({"a": [str(v) for v in a], "b": [str(v) for v in b], "product": [str(v) for v in po.poly_mul(a, b)]})
+    dm = []
+    for seed, nf, n, c in ((50, 40, 8, 1), (51, 33, 5, 7), (52, 8, 8, 3), (53, 5, 8, 1), (54, 9, 1, P - 1), (55, 64, 16, 0), (56, 300, 7, 1 << 100)):
+        f = po.splitmix_elems(seed, nf)
+        q, r = po.poly_divmod_zerofier(f, n, c)
+        # f == q·(X^n − c) + r
+        z = [(-c) % P] + [0] * (n - 1) + [1]
+        back = po.poly_mul(q, z) if q else []
+        back = [((back[i] if i < len(back) else 0) + (r[i] if i < n else 0)) % P for i in range(max(len(back), n))]
+        assert back[:nf] == f and not any(back[nf:])
+        dm.append({"seed": seed, "nf": nf, "n": n, "c": str(c), "q": [str(v) for v in q], "r": [str(v) for v in r]})
+    zd = []
+    for seed, log_n, log_e, c, off in ((60, 3, 2, 1, G), (61, 4, 1, 5, pow(G, 3, P)), (62, 5, 0, 1, G), (63, 0, 4, 9, 7)):
+        # numerator that vanishes on the zerofier's roots times a quotient: the result is then a polynomial's evaluations
+        n = 1 << log_n
+        qpoly = po.splitmix_elems(seed, n)
+        f = po.poly_mul(qpoly, [(-c) % P] + [0] * (n - 1) + [1])
+        N = n << log_e
+        while N < len(f):
+            N <<= 1
+        cw = po.coset_lde((f + [0] * N)[:N], 0, off)
+        quo = po.coset_zerofier_div(cw, log_n, c, off)
+        assert quo == po.coset_lde((qpoly + [0] * N)[:N], 0, off)
+        zd.append({"seed": seed, "log_n": log_n, "log_N": N.bit_length() - 1, "c": str(c), "offset": str(off), "cw": [str(v) for v in cw],
+                   "quotient": [str(v) for v in quo]})
+    dump("poly_vectors.json", {"mul": mul, "divmod_zerofier": dm, "coset_zerofier_div": zd})
+
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["poly"]:
+        poly_goldens()
+    else:
+        main()
