@@ -108,6 +108,7 @@ int32_t sh_ctx_destroy(sh_ctx* c) {
     if (c->h_mail) (void)hipHostFree(c->h_mail);
     if (c->h_batch) (void)hipHostFree(c->h_batch);
     if (c->h_chain) (void)hipHostFree(c->h_chain);
+    if (c->h_query) (void)hipHostFree(c->h_query);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SH_OK;

@@ -85,39 +85,72 @@ static int32_t fail_gave_up(sh_ctx* c, uint32_t round, uint32_t gen, uint32_t re
                     hd[4] & 0xffff, hd[4] >> 16, hd[5], hd[6], *reinterpret_cast<volatile uint32_t*>(c->h_chain + (hd[3] & 0x7fffffffu)));
 }
 
+// How many levels the next launch of a forest reduction takes off B trees of 2^lg digests each, and with which kernel.
+// Wide levels: one 2^step-node subtree per lane; from 2^17 digests down: four lanes per compression, levels in LDS —
+// full workgroups (2^9 digests) while there is work, balanced launches once it is latency only.
+uint32_t forest_step(uint32_t lg, size_t B, bool* quad) {
+    const size_t total = B << lg;
+    if (total > ((size_t)1 << QUAD_MAX_LOG_COUNT)) {
+        const uint32_t over = ilog2(total) - QUAD_MAX_LOG_COUNT;
+        uint32_t step = over < 3 ? over : 3;
+        *quad = false;
+        return step > lg ? lg : step;
+    }
+    *quad = true;
+    return lg <= QUAD_MAX_LOG_CHUNK ? lg : (total >= ((size_t)1 << 14) ? QUAD_MAX_LOG_CHUNK : (lg + 1) / 2);
+}
+// digests that the launches of a forest reduction write below the roots (what a LevelStore must hold for it)
+static size_t forest_store_need(uint32_t lg, size_t B) {
+    size_t need = 0;
+    while (lg) { bool q; lg -= forest_step(lg, B, &q); if (lg) need += B << lg; }
+    return need;
+}
+// Keeps what the commit's kernels write on the way up a tree (CommitKeep, api_internal.h): every round owns a fixed range of
+// one arena, so a round that is enqueued a second time writes to the same places.
+struct LevelStore {
+    digest64* base = nullptr;
+    std::vector<size_t> round_off;
+    size_t cur = 0;
+    CommitKeep::Tree* tree = nullptr;
+    void begin_round(uint32_t r, CommitKeep::Tree* t) { cur = round_off[r]; tree = t; tree->stored.clear(); }
+    digest64* take(size_t count, uint32_t level) { digest64* p = base + cur; cur += count; tree->stored.push_back({level, p}); return p; }
+};
+
 // Forest reduction: B trees of 2^lg digests each, back to back at `cur` -> B roots in the round's record + sequence word.
-// Wide levels: one 2^K-node subtree per lane; from 2^17 digests down: four lanes per compression, levels in LDS.
-static int32_t enqueue_forest_reduce(sh_ctx* c, const digest64* cur, digest64* other, digest64* self, uint32_t lg, size_t B, uint8_t* d_rec, uint32_t gen, const uint32_t* d_abort) {
+// Without a store the launches ping-pong between `other` and `self` (the buffer `cur` lives in); with one, every launch's
+// output stays: `level0` = log2 of the leaves under one digest of `cur`.
+static int32_t enqueue_forest_reduce(sh_ctx* c, const digest64* cur, digest64* other, digest64* self, uint32_t lg, size_t B, uint8_t* d_rec, uint32_t gen, const uint32_t* d_abort,
+                                     LevelStore* store = nullptr, uint32_t level0 = 0) {
     uint64_t* rec_roots = reinterpret_cast<uint64_t*>(d_rec);
     uint32_t* rec_seq = reinterpret_cast<uint32_t*>(d_rec + B * 64);
     if (lg == 0) { HIPCHK(launch_publish_digests(cur, B, rec_roots, rec_seq, gen, c->stream, d_abort)); return SH_OK; }
     while (lg > 0) {
         const size_t total = B << lg;
-        digest64* out = other;
-        uint32_t step;
-        if (total > ((size_t)1 << QUAD_MAX_LOG_COUNT)) {
-            const uint32_t over = ilog2(total) - QUAD_MAX_LOG_COUNT;
-            step = over < 3 ? over : 3;
-            if (step > lg) step = lg;
+        bool quad;
+        const uint32_t step = forest_step(lg, B, &quad);
+        level0 += step;
+        if (!quad) {
             if (step == lg) {                                      // B > 2^17 trees: finish them lane-per-subtree, then publish
-                HIPCHK(launch_node_subtree(cur, out, total >> step, step, c->stream));
-                HIPCHK(launch_publish_digests(out, B, rec_roots, rec_seq, gen, c->stream, d_abort));
+                HIPCHK(launch_node_subtree(cur, other, total >> step, step, c->stream));
+                HIPCHK(launch_publish_digests(other, B, rec_roots, rec_seq, gen, c->stream, d_abort));
                 return SH_OK;
             }
+            digest64* out = store ? store->take(total >> step, level0) : other;
             HIPCHK(launch_node_subtree(cur, out, total >> step, step, c->stream));
-        } else {
-            step = lg <= QUAD_MAX_LOG_CHUNK ? lg : (total >= ((size_t)1 << 14) ? QUAD_MAX_LOG_CHUNK : (lg + 1) / 2);   // full workgroups while there is work; balanced launches once it is latency only
-            if (step == lg) {
-                if (B == 1) HIPCHK(launch_quad_reduce(cur, c->d_root, total, step, rec_roots, gen, c->stream, nullptr, 0, d_abort));
-                else {
-                    c->batch_done_total += (uint32_t)B;
-                    HIPCHK(launch_quad_reduce(cur, reinterpret_cast<digest64*>(d_rec), total, step, reinterpret_cast<uint64_t*>(d_rec + B * 64 - 64), gen, c->stream,
-                                              c->d_flag + 16, c->batch_done_total, d_abort));
-                }
-                return SH_OK;
-            }
-            HIPCHK(launch_quad_reduce(cur, out, total, step, nullptr, 0, c->stream, nullptr, 0, d_abort));
+            cur = out; other = self; self = out; lg -= step;
+            continue;
         }
+        if (step == lg) {
+            if (B == 1) HIPCHK(launch_quad_reduce(cur, c->d_root, total, step, rec_roots, gen, c->stream, nullptr, 0, d_abort));
+            else {
+                c->batch_done_total += (uint32_t)B;
+                HIPCHK(launch_quad_reduce(cur, reinterpret_cast<digest64*>(d_rec), total, step, reinterpret_cast<uint64_t*>(d_rec + B * 64 - 64), gen, c->stream,
+                                          c->d_flag + 16, c->batch_done_total, d_abort));
+            }
+            return SH_OK;
+        }
+        digest64* out = store ? store->take(total >> step, level0) : other;
+        HIPCHK(launch_quad_reduce(cur, out, total, step, nullptr, 0, c->stream, nullptr, 0, d_abort));
         cur = out; other = self; self = out; lg -= step;
     }
     return SH_OK;
@@ -128,14 +161,15 @@ typedef std::function<int32_t(uint32_t r, const uint8_t* roots, bool want, fp* a
 
 // The commit of B equal-length codewords stored back to back, rounds in lock step (B = 1: one codeword).
 // `keep`: when set (B == 1), every round's codeword stays resident (round r >= 1 at offset N - N/2^(r-1) of one N-element
-// arena, instead of the two ping-pong buffers) and its device pointer is recorded — the query phase opens them afterwards.
+// arena, instead of the two ping-pong buffers), and so does every digest array that the round's kernels write on the way up
+// its tree (SCR_LEVELS instead of the two ping-pong digest buffers) — the query phase opens paths from them afterwards.
 static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, const sh_fri_params* prm, const RoundFn& fn,
-                               uint64_t* last_out, size_t* last_len, std::vector<const fp*>* keep) {
+                               uint64_t* last_out, size_t* last_len, CommitKeep* keep) {
     const uint32_t log_N = ilog2(N);
     fp off;
     SHCHK(check_params(prm, &off));
     const uint32_t R = sh_fri_num_rounds(N, prm->expansion, prm->num_colinearity_tests);
-    if (keep) { keep->clear(); keep->push_back(d_cws); }
+    if (keep) { keep->cws.assign(1, d_cws); keep->trees.assign(R ? R : 1, CommitKeep::Tree()); keep->trees[0].lg = log_N; }
     if (R == 0) {
         HIPCHK(hipMemcpyAsync(last_out, d_cws, B * N * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -161,9 +195,35 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
         const uint32_t lg = ilog2(len);
         return K < lg ? K : lg;
     };
+    static const bool use_round_wg = getenv("STARK_NO_ROUND_WG") == nullptr;
+    // tree of round r: 2^lg_tree leaves per codeword; `small`: the fused one-launch round (k_round_wg); K: leaves under one
+    // digest of the round's first kernel (== lg_tree when the tree ends in it)
+    struct RoundShape { uint32_t lg_tree; bool small; uint32_t K; size_t first; };
+    auto shape_of = [&](uint32_t r) {
+        RoundShape sh;
+        sh.lg_tree = log_N - r;
+        sh.small = use_round_wg && (B << sh.lg_tree) <= ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL) && sh.lg_tree >= 1;
+        sh.K = sh.small ? (sh.lg_tree < 7 ? sh.lg_tree : 7) : leaf_k((size_t)1 << sh.lg_tree);
+        sh.first = sh.K < sh.lg_tree ? (B << sh.lg_tree) >> sh.K : 0;
+        return sh;
+    };
     const size_t dig0 = (B * N) >> leaf_k(N);
-    SHCHK(ensure_scratch(c, SCR_DIG_A, dig0 * sizeof(digest64), &digA));
-    SHCHK(ensure_scratch(c, SCR_DIG_B, (dig0 / 2 ? dig0 / 2 : 1) * sizeof(digest64), &digB));
+    LevelStore store;
+    if (keep) {
+        size_t need = 0;
+        for (uint32_t r = 0; r < R; ++r) {
+            const RoundShape sh = shape_of(r);
+            store.round_off.push_back(need);
+            need += sh.first + forest_store_need(sh.lg_tree - sh.K, B);
+        }
+        void* lv;
+        SHCHK(ensure_scratch(c, SCR_LEVELS, (need ? need : 1) * sizeof(digest64), &lv));
+        store.base = (digest64*)lv;
+        digA = digB = nullptr;
+    } else {
+        SHCHK(ensure_scratch(c, SCR_DIG_A, dig0 * sizeof(digest64), &digA));
+        SHCHK(ensure_scratch(c, SCR_DIG_B, (dig0 / 2 ? dig0 / 2 : 1) * sizeof(digest64), &digB));
+    }
     SHCHK(ensure_scratch(c, SCR_C0, B * sizeof(fp), &d_c0));
     uint32_t gen = (c->chain_gen + 1) & 0x7fffffffu;
     if (gen == 0) gen = 1;
@@ -188,12 +248,15 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
     auto cw_of = [&](uint32_t r) -> fp* {          // codeword r, r >= 1: arena offset N - N/2^(r-1), or the ping-pong buffers
         return keep ? (fp*)arena + (N - (N >> (r - 1))) : (fp*)(((r - 1) & 1) ? bufY : bufX);
     };
-    if (keep) for (uint32_t r = 1; r < R; ++r) keep->push_back(cw_of(r));
+    if (keep) for (uint32_t r = 1; r < R; ++r) { keep->cws.push_back(cw_of(r)); keep->trees[r].lg = log_N - r; }
     uint32_t enq = 0;                              // rounds enqueued so far
-    static const bool use_round_wg = getenv("STARK_NO_ROUND_WG") == nullptr;
     auto enqueue_round = [&]() -> int32_t {
         const uint32_t r = enq;
         uint8_t* rec = c->d_chain + lay.roots(r);
+        const RoundShape sh = shape_of(r);
+        LevelStore* st = keep ? &store : nullptr;
+        digest64 *first = (digest64*)digA, *other = (digest64*)digB;
+        if (keep) { store.begin_round(r, &keep->trees[r]); first = sh.first ? store.take(sh.first, sh.K) : nullptr; other = nullptr; }
         // small rounds: the whole round (wait, fold, leaf hash, bottom 7 levels) is one launch, plus one for the levels above
         auto small_round = [&](bool fold, const fp* in, fp* out, uint32_t lg_tree) -> int32_t {
             const size_t blocks = ((B << lg_tree) + 127) / 128;
@@ -205,30 +268,32 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
                                       (fp*)d_c0, B, d_abort, hd_abort, timeout_ticks, c->stream));
             HIPCHK(launch_round_wg(fold, in, out, lg_tree, B, poll_inside ? reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)) : nullptr, gen,
                                    poll_inside ? reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)) : nullptr, (const fp*)d_c0, d_abort, hd_abort, timeout_ticks, tw_inv, log_N,
-                                   fold ? r - 1 : 0, (digest64*)digA, reinterpret_cast<uint64_t*>(rec), reinterpret_cast<uint32_t*>(rec + B * 64), c->d_flag + 16, target,
+                                   fold ? r - 1 : 0, first, reinterpret_cast<uint64_t*>(rec), reinterpret_cast<uint32_t*>(rec + B * 64), c->d_flag + 16, target,
                                    c->stream));
-            if (lg_tree > 7) SHCHK(enqueue_forest_reduce(c, (const digest64*)digA, (digest64*)digB, (digest64*)digA, lg_tree - 7, B, rec, gen, d_abort));
+            if (lg_tree > 7) SHCHK(enqueue_forest_reduce(c, first, other, first, lg_tree - 7, B, rec, gen, d_abort, st, 7));
             return SH_OK;
         };
         if (r == 0) {
-            if (use_round_wg && (B << log_N) <= ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL) && log_N >= 1) SHCHK(small_round(false, d_cws, nullptr, log_N));
+            if (sh.small) SHCHK(small_round(false, d_cws, nullptr, log_N));
             else {
-                const uint32_t K = leaf_k(N);
-                HIPCHK(launch_leaf_subtree(d_cws, (digest64*)digA, (B * N) >> K, K, c->stream));
-                SHCHK(enqueue_forest_reduce(c, (const digest64*)digA, (digest64*)digB, (digest64*)digA, log_N - K, B, rec, gen, d_abort));
+                const uint32_t K = sh.K;
+                digest64* dst = first ? first : c->d_root;              // a tree that ends in its lanes (N <= 2^K): one digest, the root
+                HIPCHK(launch_leaf_subtree(d_cws, dst, (B * N) >> K, K, c->stream));
+                SHCHK(enqueue_forest_reduce(c, dst, other, dst, log_N - K, B, rec, gen, d_abort, st, K));
             }
         } else {
             const size_t L = N >> (r - 1), half = L / 2;
             const fp* in = r == 1 ? d_cws : cw_of(r - 1);
             fp* next = cw_of(r);
             if (guard.waits < r) guard.waits = r;
-            if (use_round_wg && B * half <= ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL)) SHCHK(small_round(true, in, next, ilog2(half)));
+            if (sh.small) SHCHK(small_round(true, in, next, ilog2(half)));
             else {
                 HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)),
                                       (fp*)d_c0, B, d_abort, hd_abort, timeout_ticks, c->stream));
-                const uint32_t K = leaf_k(half);
-                HIPCHK(launch_fold_leaf_subtree(in, L, B, (const fp*)d_c0, fp_zero(), tw_inv, log_N, r - 1, next, (digest64*)digA, K, c->stream, d_abort));
-                SHCHK(enqueue_forest_reduce(c, (const digest64*)digA, (digest64*)digB, (digest64*)digA, ilog2(half) - K, B, rec, gen, d_abort));
+                const uint32_t K = sh.K;
+                digest64* dst = first ? first : c->d_root;
+                HIPCHK(launch_fold_leaf_subtree(in, L, B, (const fp*)d_c0, fp_zero(), tw_inv, log_N, r - 1, next, dst, K, c->stream, d_abort));
+                SHCHK(enqueue_forest_reduce(c, dst, other, dst, ilog2(half) - K, B, rec, gen, d_abort, st, K));
             }
         }
         ++enq;
@@ -308,7 +373,7 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
 }
 
 int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_params* prm, sh_transcript_cb cb, void* user,
-                       uint8_t* roots_out, uint64_t* last_out, size_t* last_len, std::vector<const fp*>* keep) {
+                       uint8_t* roots_out, uint64_t* last_out, size_t* last_len, CommitKeep* keep) {
     CTXCHK(c);
     if (!d_cw || !cb || !roots_out || !last_out || !last_len) return sh_fail(SH_EINVAL, "fri_commit: null pointer");
     if (!is_pow2(N)) return sh_fail(SH_EINVAL, "fri_commit: N must be a power of two");

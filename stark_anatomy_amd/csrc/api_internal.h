@@ -61,6 +61,8 @@ struct sh_ctx {
     uint8_t* h_chain = nullptr;                  // pinned, device-mapped: root / fold-constant records of a commit's rounds (api_fri.hip)
     uint8_t* d_chain = nullptr;                  // device view of h_chain
     size_t chain_bytes = 0;
+    uint8_t* h_query = nullptr;                  // pinned staging of the query phase (paths | values | indices | tree table)
+    size_t h_query_bytes = 0;
     uint64_t chain_retries = 0;                  // rounds enqueued a second time because a wait kernel ran out of spin
     uint32_t chain_gen = 0;                      // generation number of the last commit (the records' sequence value)
 };
@@ -95,7 +97,16 @@ int32_t fetch_root(sh_ctx* c, uint8_t root[64]);
 int32_t noalloc_init_device(int device);
 // api_fri.hip
 int32_t check_params(const sh_fri_params* p, fp* offset);
+uint32_t forest_step(uint32_t lg, size_t B, bool* quad);   // levels the next launch of a forest reduction takes off B trees of 2^lg digests; which kernel
+// What a commit leaves resident on the device for the query phase (one codeword): the codeword of every round and, per
+// round's tree, the digest arrays its kernels wrote on the way up — (level, array) with 2^level leaves under each digest,
+// ascending.  The levels in between are recomputed per opened path (k_open_paths).
+struct CommitKeep {
+    std::vector<const fp*> cws;
+    struct Tree { uint32_t lg = 0; std::vector<std::pair<uint32_t, const digest64*>> stored; };
+    std::vector<Tree> trees;
+};
 int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_params* prm, sh_transcript_cb cb, void* user,
-                       uint8_t* roots_out, uint64_t* last_out, size_t* last_len, std::vector<const fp*>* keep = nullptr);
+                       uint8_t* roots_out, uint64_t* last_out, size_t* last_len, CommitKeep* keep = nullptr);
 struct PsCbState { sh_proofstream* ps; };
 int32_t ps_callback(void* user, uint32_t round, const uint8_t root[64], int32_t want_alpha, uint64_t alpha_out[2]);

@@ -4,25 +4,57 @@
 
 // ------------------------------------------------------------------ query phase: batched openings, prove, verify
 // (definitions G9-G12 in DESIGN.md §9 — the reference holds none of this.)
-// All levels of the tree whose L leaf digests already sit at lvl[0..L): level l at offset 2L - (2L >> l).
-static int32_t build_levels(sh_ctx* c, digest64* lvl, size_t L) {
-    size_t n = L;
-    while (n > 2) {
-        HIPCHK(launch_node_subtree(lvl, lvl + n, n >> 1, 1, c->stream));
-        lvl += n; n >>= 1;
-    }
-    return SH_OK;
-}
-// paths (n_idx x depth x 64 B, host) of `h_idx` in the tree whose levels are at `levels`
-static int32_t gather_paths_to_host(sh_ctx* c, const digest64* levels, size_t L, const uint64_t* h_idx, size_t n_idx, uint8_t* h_paths) {
+// Paths of `h_idx` (n_idx x depth x 64 B, to the host) in ONE tree, merkle.rs:70-108.  The tree is given by its leaves'
+// preimages (d_elems: field elements, leaf = Blake2b512(le16)) or by its leaf digests (d_leaves).  Built like a commit
+// (lane-per-subtree, then four-lanes-per-compression launches), keeping the digest array every launch writes — about
+// L/2^K·64·1.15 bytes instead of all 2·L·64 — and opened by k_open_paths, which rebuilds the levels in between per path.
+static int32_t open_paths_one_tree(sh_ctx* c, const fp* d_elems, const digest64* d_leaves, size_t L, const uint64_t* h_idx, size_t n_idx, uint8_t* h_paths) {
     if (!n_idx) return SH_OK;
     const uint32_t depth = ilog2(L);
-    void *d_idx, *d_paths;
-    SHCHK(ensure_scratch(c, SCR_IDX, n_idx * 8, &d_idx));
-    SHCHK(ensure_scratch(c, SCR_PATHS, n_idx * depth * 64, &d_paths));
-    HIPCHK(hipMemcpyAsync(d_idx, h_idx, n_idx * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(launch_gather_paths(levels, L, (const uint64_t*)d_idx, n_idx, (digest64*)d_paths, c->stream));
-    HIPCHK(hipMemcpyAsync(h_paths, d_paths, n_idx * depth * 64, hipMemcpyDeviceToHost, c->stream));
+    OpenTree T;
+    memset(&T, 0, sizeof T);
+    T.cw = d_elems;
+    T.log_L = depth;
+    uint32_t K = 0;
+    if (d_elems) { K = leaf_subtree_k(depth); if (K >= depth) K = depth - 1; }
+    // sizes first: one allocation
+    size_t need = d_elems ? (L >> K) : 0;
+    for (uint32_t lg = depth - K;;) { bool q; const uint32_t st = forest_step(lg, 1, &q); if (st >= lg) break; lg -= st; need += (size_t)1 << lg; }
+    void* lv = nullptr;
+    SHCHK(ensure_scratch(c, SCR_LEVELS, (need ? need : 1) * sizeof(digest64), &lv));
+    digest64* next = (digest64*)lv;
+    const digest64* cur;
+    if (d_elems) {
+        HIPCHK(launch_leaf_subtree(d_elems, next, L >> K, K, c->stream));
+        cur = next; next += L >> K;
+    } else cur = d_leaves;
+    T.level[0] = K; T.stored[0] = cur; T.n_stored = 1;
+    uint32_t level = K;
+    for (uint32_t lg = depth - K;;) {
+        bool quad;
+        const uint32_t st = forest_step(lg, 1, &quad);
+        if (st >= lg) break;                                             // the levels up to the root are the path kernel's last segment
+        const size_t n_out = (size_t)1 << (lg - st);
+        if (quad) HIPCHK(launch_quad_reduce(cur, next, (size_t)1 << lg, st, nullptr, 0, c->stream));
+        else HIPCHK(launch_node_subtree(cur, next, n_out, st, c->stream));
+        lg -= st; level += st;
+        if (T.n_stored >= OPEN_MAX_STORED) return sh_fail(SH_EHIP, "merkle_open: internal error: too many digest levels");
+        T.level[T.n_stored] = level; T.stored[T.n_stored++] = next;
+        cur = next; next += n_out;
+    }
+    T.idx_off = 0; T.n_idx = (uint32_t)n_idx; T.wg_off = 0; T.path_off = 0;
+    const size_t n_seg = T.n_stored + ((T.level[0] > 0) ? 1 : 0), n_wg = n_idx * n_seg;
+    if (n_wg > 0x7fffffffu) return sh_fail(SH_EINVAL, "merkle_open: too many indices for one launch");
+    const size_t off_idx = n_idx * depth * sizeof(digest64), off_tree = (off_idx + n_idx * 8 + 15) & ~(size_t)15, total = off_tree + sizeof(OpenTree);
+    void* dq;
+    SHCHK(ensure_scratch(c, SCR_PATHS, total, &dq));
+    uint8_t* dqb = (uint8_t*)dq;
+    HIPCHK(hipMemcpyAsync(dqb + off_idx, h_idx, n_idx * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dqb + off_tree, &T, sizeof T, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                             // T lives on this stack frame
+    HIPCHK(launch_open_paths(reinterpret_cast<const OpenTree*>(dqb + off_tree), &T, 1, (uint32_t)n_wg, reinterpret_cast<const uint64_t*>(dqb + off_idx),
+                             reinterpret_cast<digest64*>(dqb), nullptr, c->stream));
+    HIPCHK(hipMemcpyAsync(h_paths, dqb, off_idx, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return SH_OK;
 }
@@ -73,9 +105,9 @@ static int32_t fri_prove_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_p
     std::vector<uint8_t> roots((size_t)(R ? R : 1) * 64);
     std::vector<uint64_t> last(2 * (N >> (R ? R - 1 : 0)));          // the last codeword only (N/2^(R-1) elements)
     size_t last_len = 0;
-    std::vector<const fp*> cws;
+    CommitKeep kept;
     PsCbState st{ps};
-    SHCHK(fri_commit_dev(c, d_cw, N, prm, ps_callback, &st, roots.data(), last.data(), &last_len, &cws));
+    SHCHK(fri_commit_dev(c, d_cw, N, prm, ps_callback, &st, roots.data(), last.data(), &last_len, &kept));
     SHCHK(sh_proofstream_push_codeword(ps, last.data(), last_len));
     if (R < 2) return SH_OK;                                   // a single codeword: nothing to test against
     uint8_t seed[32];
@@ -86,44 +118,66 @@ static int32_t fri_prove_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_p
     *n_top = top.size();
 
     // Per tree r: openings wanted = a_r, b_r (tests of round r, r < R-1) and c_(r-1) (tests of round r-1, r >= 1).
-    // Each tree's levels are built once (leaf hashes + K = 1 node levels into one buffer) and all its paths and leaf
-    // values come back in one gather each.
-    std::vector<std::vector<uint64_t>> idx(R), vals(R);
-    std::vector<std::vector<uint8_t>> paths(R);
+    // All trees go through ONE launch (k_open_paths: paths from the digest arrays the commit left behind, opened values
+    // alongside), one copy in and one copy out.
+    std::vector<OpenTree> trees(R);
+    size_t n_idx_total = 0, n_path = 0, n_wg = 0;
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t depth = ilog2(N >> r);
+        const size_t n_idx = (size_t)t * ((r + 1 < R ? 2 : 0) + (r >= 1 ? 1 : 0));
+        OpenTree& T = trees[r];
+        memset(&T, 0, sizeof T);
+        T.cw = kept.cws[r];
+        T.log_L = depth;
+        const auto& stored = kept.trees[r].stored;
+        if (stored.size() > OPEN_MAX_STORED) return sh_fail(SH_EHIP, "fri_prove: internal error: more digest levels kept than the path kernel takes");
+        for (const auto& lv : stored) if (lv.first < depth) { T.level[T.n_stored] = lv.first; T.stored[T.n_stored++] = lv.second; }
+        T.idx_off = (uint32_t)n_idx_total; T.n_idx = (uint32_t)n_idx;
+        T.wg_off = (uint32_t)n_wg; T.path_off = n_path;
+        n_idx_total += n_idx; n_path += n_idx * depth; n_wg += n_idx * (T.n_stored + ((T.n_stored == 0 || T.level[0] > 0) ? 1 : 0));
+    }
+    if (n_wg > 0x7fffffffu) return sh_fail(SH_EINVAL, "fri_prove: too many openings for one launch");
+    const size_t off_vals = n_path * sizeof(digest64), off_idx = off_vals + n_idx_total * sizeof(fp);
+    const size_t off_trees = (off_idx + n_idx_total * 8 + 15) & ~(size_t)15, total = off_trees + R * sizeof(OpenTree);
+    void* dq;
+    SHCHK(ensure_scratch(c, SCR_PATHS, total, &dq));
+    if (c->h_query_bytes < total) {
+        if (c->h_query) { HIPCHK(hipHostFree(c->h_query)); c->h_query = nullptr; c->h_query_bytes = 0; }
+        HIPCHK(hipHostMalloc((void**)&c->h_query, total, hipHostMallocDefault));
+        c->h_query_bytes = total;
+    }
+    uint8_t* hq = c->h_query;
+    uint64_t* h_idx = reinterpret_cast<uint64_t*>(hq + off_idx);
     for (uint32_t r = 0; r < R; ++r) {
         const size_t L = N >> r;
+        uint64_t* ix = h_idx + trees[r].idx_off;
         if (r + 1 < R) {
-            for (uint32_t s_ = 0; s_ < t; ++s_) idx[r].push_back(top[s_] % (L / 2));
-            for (uint32_t s_ = 0; s_ < t; ++s_) idx[r].push_back(top[s_] % (L / 2) + L / 2);
+            for (uint32_t s_ = 0; s_ < t; ++s_) *ix++ = top[s_] % (L / 2);
+            for (uint32_t s_ = 0; s_ < t; ++s_) *ix++ = top[s_] % (L / 2) + L / 2;
         }
-        if (r >= 1) for (uint32_t s_ = 0; s_ < t; ++s_) idx[r].push_back(top[s_] % L);        // c of round r-1: top % (L_(r-1)/2)
-        const size_t n_idx = idx[r].size();
-        const uint32_t depth = ilog2(L);
-        void *lv, *d_idx, *d_vals;
-        SHCHK(ensure_scratch(c, SCR_LEVELS, 2 * L * sizeof(digest64), &lv));
-        HIPCHK(launch_hash_leaves(cws[r], (digest64*)lv, L, c->stream));
-        SHCHK(build_levels(c, (digest64*)lv, L));
-        paths[r].resize(n_idx * depth * 64);
-        SHCHK(gather_paths_to_host(c, (const digest64*)lv, L, idx[r].data(), n_idx, paths[r].data()));
-        SHCHK(ensure_scratch(c, SCR_IDX, n_idx * 8, &d_idx));              // still holds idx[r] from the call above
-        SHCHK(ensure_scratch(c, SCR_PATHS, n_idx * sizeof(fp), &d_vals));
-        HIPCHK(launch_gather_elems(cws[r], (const uint64_t*)d_idx, n_idx, (fp*)d_vals, c->stream));
-        vals[r].resize(2 * n_idx);
-        HIPCHK(hipMemcpyAsync(vals[r].data(), d_vals, n_idx * sizeof(fp), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (r >= 1) for (uint32_t s_ = 0; s_ < t; ++s_) *ix++ = top[s_] % L;                  // c of round r-1: top % (L_(r-1)/2)
     }
+    memcpy(hq + off_trees, trees.data(), R * sizeof(OpenTree));
+    uint8_t* dqb = (uint8_t*)dq;
+    HIPCHK(hipMemcpyAsync(dqb + off_idx, hq + off_idx, total - off_idx, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_open_paths(reinterpret_cast<const OpenTree*>(dqb + off_trees), trees.data(), R, (uint32_t)n_wg, reinterpret_cast<const uint64_t*>(dqb + off_idx),
+                             reinterpret_cast<digest64*>(dqb), reinterpret_cast<fp*>(dqb + off_vals), c->stream));
+    if (off_idx) HIPCHK(hipMemcpyAsync(hq, dqb, off_idx, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint64_t* h_vals = reinterpret_cast<const uint64_t*>(hq + off_vals);
     for (uint32_t r = 0; r + 1 < R; ++r) {                                  // G11: per round, t value triples, then 3t paths
         const uint32_t d0 = ilog2(N >> r), d1 = d0 - 1;
         const size_t c_off = (r + 2 < R) ? 2 * (size_t)t : 0;               // where tree r+1 keeps its c entries
+        const uint64_t *v0 = h_vals + 2 * (size_t)trees[r].idx_off, *v1 = h_vals + 2 * (size_t)trees[r + 1].idx_off;
+        const uint8_t *p0 = hq + trees[r].path_off * 64, *p1 = hq + trees[r + 1].path_off * 64;
         for (uint32_t s_ = 0; s_ < t; ++s_) {
-            uint64_t abc[6] = {vals[r][2 * s_], vals[r][2 * s_ + 1], vals[r][2 * (t + s_)], vals[r][2 * (t + s_) + 1],
-                               vals[r + 1][2 * (c_off + s_)], vals[r + 1][2 * (c_off + s_) + 1]};
+            uint64_t abc[6] = {v0[2 * s_], v0[2 * s_ + 1], v0[2 * (t + s_)], v0[2 * (t + s_) + 1], v1[2 * (c_off + s_)], v1[2 * (c_off + s_) + 1]};
             SHCHK(sh_proofstream_push_leaves(ps, abc, 3));
         }
         for (uint32_t s_ = 0; s_ < t; ++s_) {
-            SHCHK(sh_proofstream_push_path(ps, paths[r].data() + (size_t)s_ * d0 * 64, d0));
-            SHCHK(sh_proofstream_push_path(ps, paths[r].data() + (size_t)(t + s_) * d0 * 64, d0));
-            SHCHK(sh_proofstream_push_path(ps, paths[r + 1].data() + (c_off + s_) * d1 * 64, d1));
+            SHCHK(sh_proofstream_push_path(ps, p0 + (size_t)s_ * d0 * 64, d0));
+            SHCHK(sh_proofstream_push_path(ps, p0 + (size_t)(t + s_) * d0 * 64, d0));
+            SHCHK(sh_proofstream_push_path(ps, p1 + (c_off + s_) * d1 * 64, d1));
         }
     }
     return SH_OK;
@@ -158,21 +212,16 @@ int32_t sh_dev_merkle_open_elems_batch(sh_ctx* c, const uint64_t* d_elems, size_
     CTXCHK(c);
     if (!d_elems || (!indices && n_idx) || (!paths && n_idx)) return sh_fail(SH_EINVAL, "sh_dev_merkle_open_elems_batch: null pointer");
     SHCHK(check_open_args("sh_dev_merkle_open_elems_batch", L, indices, n_idx));
-    void* lv;
-    SHCHK(ensure_scratch(c, SCR_LEVELS, 2 * L * sizeof(digest64), &lv));
-    HIPCHK(launch_hash_leaves((const fp*)d_elems, (digest64*)lv, L, c->stream));
-    SHCHK(build_levels(c, (digest64*)lv, L));
-    return gather_paths_to_host(c, (const digest64*)lv, L, indices, n_idx, paths);
+    return open_paths_one_tree(c, (const fp*)d_elems, nullptr, L, indices, n_idx, paths);
 }
 int32_t sh_merkle_open_batch(sh_ctx* c, const uint8_t* leaves, size_t L, const uint64_t* indices, size_t n_idx, uint8_t* paths) {
     CTXCHK(c);
     if (!leaves || (!indices && n_idx) || (!paths && n_idx)) return sh_fail(SH_EINVAL, "sh_merkle_open_batch: null pointer");
     SHCHK(check_open_args("sh_merkle_open_batch", L, indices, n_idx));
-    void* lv;
-    SHCHK(ensure_scratch(c, SCR_LEVELS, 2 * L * sizeof(digest64), &lv));
-    HIPCHK(hipMemcpyAsync(lv, leaves, L * 64, hipMemcpyHostToDevice, c->stream));
-    SHCHK(build_levels(c, (digest64*)lv, L));
-    return gather_paths_to_host(c, (const digest64*)lv, L, indices, n_idx, paths);
+    void* dl;
+    SHCHK(ensure_scratch(c, SCR_IO_C, L * sizeof(digest64), &dl));
+    HIPCHK(hipMemcpyAsync(dl, leaves, L * 64, hipMemcpyHostToDevice, c->stream));
+    return open_paths_one_tree(c, nullptr, (const digest64*)dl, L, indices, n_idx, paths);
 }
 int32_t sh_fri_sample_indices(const uint8_t seed[32], uint64_t size, uint64_t reduced_size, uint32_t number, uint64_t* out) {
     try {

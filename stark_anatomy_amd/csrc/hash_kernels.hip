@@ -303,35 +303,3 @@ hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* 
                        log_n_table, tw_shift, out, digests, n_out, K, d_abort);
     return hipGetLastError();
 }
-
-// ---------------------------------------------------------------------------------------------
-// Query phase: authentication paths by gather from the persisted levels of a tree.
-// `levels` = level 0 (L digests) | level 1 (L/2) | ... | level depth-1 (2 digests); level l starts at 2L - (2L >> l).
-// out[q][l] = sibling of index[q]'s ancestor at level l — the order MerkleTree::open returns (merkle.rs:104-107).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gather_paths(const digest64* __restrict__ levels, size_t L, uint32_t depth, const uint64_t* __restrict__ index,
-                                                      size_t n_idx, digest64* __restrict__ out) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_idx * depth * 4) return;
-    const uint32_t part = (uint32_t)(t & 3);
-    const size_t ql = t >> 2, q = ql / depth;
-    const uint32_t l = (uint32_t)(ql % depth);
-    const size_t node = (index[q] >> l) ^ 1;
-    reinterpret_cast<uint4*>(out + ql)[part] = reinterpret_cast<const uint4*>(levels + (2 * L - ((2 * L) >> l)) + node)[part];
-}
-__global__ __launch_bounds__(256) void k_gather_elems(const fp* __restrict__ src, const uint64_t* __restrict__ index, size_t n, fp* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = src[index[i]];
-}
-hipError_t launch_gather_paths(const digest64* levels, size_t L, const uint64_t* d_index, size_t n_idx, digest64* out, hipStream_t s) {
-    if (L < 2 || (L & (L - 1))) return hipErrorInvalidValue;
-    if (!n_idx) return hipSuccess;
-    uint32_t depth = 0; while (((size_t)1 << depth) < L) ++depth;
-    hipLaunchKernelGGL(k_gather_paths, dim3(grid_for(n_idx * depth * 4, 256)), dim3(256), 0, s, levels, L, depth, d_index, n_idx, out);
-    return hipGetLastError();
-}
-hipError_t launch_gather_elems(const fp* src, const uint64_t* d_index, size_t n, fp* out, hipStream_t s) {
-    if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_gather_elems, dim3(grid_for(n, 256)), dim3(256), 0, s, src, d_index, n, out);
-    return hipGetLastError();
-}

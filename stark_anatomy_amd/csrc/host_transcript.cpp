@@ -198,6 +198,29 @@ inline size_t put_u128_dec(char* out, unsigned __int128 v) {               // se
     else { const uint64_t l1 = (uint64_t)(v % E19); v /= E19; n = put_u64_dec(out, (uint64_t)v); n += put_u64_dec_padded19(out + n, l1); }
     return n + put_u64_dec_padded19(out + n, l0);
 }
+// An item whose first byte is LAZY_PATH (no JSON text starts with it) still holds raw digests: write it out in place.
+const char LAZY_PATH = 0x01;
+struct ByteDec { char txt[256][4]; uint8_t len[256]; ByteDec() { for (int v = 0; v < 256; ++v) { len[v] = (uint8_t)put_u64_dec(txt[v], (uint64_t)v); txt[v][len[v]] = ','; } } };
+const ByteDec BYTE_DEC;                                                   // "0," .. "255,": one 4-byte copy per value
+void materialize(std::string& it) {
+    if (it.empty() || it[0] != LAZY_PATH) return;
+    const size_t n = (it.size() - 1) / 64;
+    const uint8_t* d = (const uint8_t*)it.data() + 1;
+    std::string s(9 + n * (10 + 64 * 4 + 3) + 2 + 4, '\0');
+    char* buf = &s[0];
+    size_t o = 9;
+    memcpy(buf, "{\"Path\":[", 9);
+    for (size_t k = 0; k < n; ++k) {
+        if (k) buf[o++] = ',';
+        memcpy(buf + o, "{\"inner\":[", 10); o += 10;
+        for (int i = 0; i < 64; ++i) { const uint8_t v = d[64 * k + i]; memcpy(buf + o, BYTE_DEC.txt[v], 4); o += BYTE_DEC.len[v] + 1; }
+        buf[o - 1] = ']'; buf[o++] = '}';                                 // the last comma becomes the bracket
+    }
+    buf[o++] = ']'; buf[o++] = '}';
+    s.resize(o);
+    it = std::move(s);
+}
+void materialize_all(std::vector<std::string>& items, size_t count) { for (size_t i = 0; i < count; ++i) materialize(items[i]); }
 std::string serialize_items(const std::vector<std::string>& items, size_t count) {   // serialize_inner, proof_stream.rs:67-69
     size_t need = 2;
     for (size_t i = 0; i < count; ++i) need += items[i].size() + 1;
@@ -324,6 +347,7 @@ int32_t sh_proofstream_free(sh_proofstream* ps) { delete ps; return SH_OK; }
 int32_t sh_proofstream_push_json(sh_proofstream* ps, const uint8_t* json, size_t len) {       // proof_stream.rs:25-27
     SH_GUARD_BEGIN
     if (!ps || (!json && len)) return sh_fail(SH_EINVAL, "sh_proofstream_push_json: null pointer");
+    if (len && json[0] == (uint8_t)LAZY_PATH) return sh_fail(SH_EINVAL, "sh_proofstream_push_json: not JSON text");   // the marker of a path kept in raw form
     ps->items.emplace_back((const char*)json, len);
     return SH_OK;
     SH_GUARD_END("sh_proofstream_push_json")
@@ -379,18 +403,12 @@ int32_t sh_proofstream_push_leaves(sh_proofstream* ps, const uint64_t* elems, si
 int32_t sh_proofstream_push_path(sh_proofstream* ps, const uint8_t* digests, size_t n) {
     SH_GUARD_BEGIN
     if (!ps || (!digests && n)) return sh_fail(SH_EINVAL, "sh_proofstream_push_path: null pointer");
-    std::string s(9 + n * (10 + 64 * 4 + 3) + 2, '\0');
-    char* buf = &s[0];
-    size_t o = 9;
-    memcpy(buf, "{\"Path\":[", 9);
-    for (size_t k = 0; k < n; ++k) {
-        if (k) buf[o++] = ',';
-        memcpy(buf + o, "{\"inner\":[", 10); o += 10;
-        for (int i = 0; i < 64; ++i) { if (i) buf[o++] = ','; o += put_u64_dec(buf + o, digests[64 * k + i]); }
-        buf[o++] = ']'; buf[o++] = '}';
-    }
-    buf[o++] = ']'; buf[o++] = '}';
-    s.resize(o);
+    // Kept as the raw digests behind a marker byte and written out as JSON when something reads the item (pull, serialize,
+    // a Fiat-Shamir digest) — as the reference's push stores the object and serialises on demand (proof_stream.rs:25-27,
+    // 38-40).  A proof's paths are most of its bytes; the prover never reads them back.
+    std::string s(1 + n * 64, '\0');
+    s[0] = LAZY_PATH;
+    if (n) memcpy(&s[1], digests, n * 64);
     ps->items.push_back(std::move(s));
     return SH_OK;
     SH_GUARD_END("sh_proofstream_push_path")
@@ -404,6 +422,7 @@ int32_t sh_proofstream_len(sh_proofstream* ps, size_t* n_items, size_t* read_ind
 int32_t sh_proofstream_pull(sh_proofstream* ps, const uint8_t** json, size_t* len) {          // proof_stream.rs:29-36
     if (!ps || !json || !len) return sh_fail(SH_EINVAL, "sh_proofstream_pull: null pointer");
     if (ps->read_index >= ps->items.size()) return sh_fail(SH_EBOUNDS, "Read index is out of bounds");
+    materialize(ps->items[ps->read_index]);
     const std::string& s = ps->items[ps->read_index++];
     *json = (const uint8_t*)s.data();
     *len = s.size();
@@ -412,6 +431,7 @@ int32_t sh_proofstream_pull(sh_proofstream* ps, const uint8_t** json, size_t* le
 int32_t sh_proofstream_serialize(sh_proofstream* ps, uint8_t* out, size_t cap, size_t* needed) {   // proof_stream.rs:38-40
     SH_GUARD_BEGIN
     if (!ps || !needed) return sh_fail(SH_EINVAL, "sh_proofstream_serialize: null pointer");
+    materialize_all(ps->items, ps->items.size());
     std::string s = serialize_items(ps->items, ps->items.size());
     *needed = s.size();
     if (out && cap >= s.size()) memcpy(out, s.data(), s.size());
@@ -459,6 +479,7 @@ int32_t sh_proofstream_prover_fiat_shamir(sh_proofstream* ps, uint8_t out[32]) {
     }
     for (; ps->absorbed < ps->items.size(); ++ps->absorbed) {
         if (ps->absorbed) ps->running->h.update((const uint8_t*)",", 1);
+        materialize(ps->items[ps->absorbed]);
         const std::string& it = ps->items[ps->absorbed];
         ps->running->h.update((const uint8_t*)it.data(), it.size());
     }
@@ -470,6 +491,7 @@ int32_t sh_proofstream_prover_fiat_shamir(sh_proofstream* ps, uint8_t out[32]) {
 int32_t sh_proofstream_verifier_fiat_shamir(sh_proofstream* ps, uint8_t out[32]) {                 // proof_stream.rs:58-64
     SH_GUARD_BEGIN
     if (!ps || !out) return sh_fail(SH_EINVAL, "sh_proofstream_verifier_fiat_shamir: null pointer");
+    materialize_all(ps->items, ps->read_index);
     std::string s = serialize_items(ps->items, ps->read_index);
     host_sha256((const uint8_t*)s.data(), s.size(), out);
     return SH_OK;

@@ -12,6 +12,21 @@ enum { FPOP_ADD = 0, FPOP_SUB = 1, FPOP_MUL = 2, FPOP_DIV = 3, FPOP_INV = 4, FPO
 // inversion, one field inversion per 2048 elements).  FPOP_INV_MONT: out = 2^128 / a, the factor that makes
 // mont_mul(x, out) = x / a.
 hipError_t launch_fp_binop(int op, const fp* a, const fp* b, fp* out, size_t n, uint32_t* d_flag, hipStream_t s);
+// ---- query_kernels.hip ----
+// One tree of a proof's query phase: the codeword under it, the digest arrays its commit left in memory (level[k] = log2
+// of the leaves under one digest of stored[k], ascending, all < log_L), and where its indices / workgroups / paths sit.
+#define OPEN_MAX_STORED 8
+struct OpenTree {
+    const fp* cw;
+    const digest64* stored[OPEN_MAX_STORED];
+    uint32_t level[OPEN_MAX_STORED];
+    uint32_t log_L, n_stored;
+    uint32_t idx_off, n_idx;             // its indices: idx[idx_off .. idx_off + n_idx); vals likewise
+    uint32_t wg_off;                     // its workgroups: wg_off + j·n_seg + segment, n_seg = n_stored + (n_stored == 0 || level[0] > 0)
+    uint64_t path_off;                   // its paths: digest path_off + j·log_L + l = sibling of index j at level l (merkle.rs:70-108 order)
+};
+// paths and the opened values themselves (vals[idx_off + j] = cw[idx[...]]) for all trees in one launch; h_trees = host copy of d_trees (checked)
+hipError_t launch_open_paths(const OpenTree* d_trees, const OpenTree* h_trees, uint32_t n_trees, uint32_t total_wgs, const uint64_t* d_idx, digest64* d_paths, fp* d_vals, hipStream_t s);
 // ---- poly_kernels.hip ----
 // z[k] = start · w^k − c, k < count   (values of the zerofier X^n − c over one period of a coset; w_mont = w·2^128)
 hipError_t launch_zerofier_values(fp* z, size_t count, fp start, fp w_mont, fp c, hipStream_t s);
@@ -34,8 +49,6 @@ void ntt_make_plan(uint32_t log_n, NttPlan* plan);
 // `data` is transformed in place; `scratch` holds n elements.
 // `batch` contiguous transforms of 2^plan.log_n elements each; `scratch` holds as many elements as `data`.
 hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s);
-hipError_t launch_gather_paths(const digest64* levels, size_t L, const uint64_t* d_index, size_t n_idx, digest64* out, hipStream_t s);
-hipError_t launch_gather_elems(const fp* src, const uint64_t* d_index, size_t n, fp* out, hipStream_t s);
 hipError_t launch_scale_powers(fp* data, size_t count, fp start_mont, fp base, hipStream_t s);
 hipError_t launch_twiddle_scale(fp* data, size_t rows, uint32_t log_cols, uint64_t row0, uint64_t col0, const fp* tw, uint32_t log_n, hipStream_t s);
 // out[j] = j < n ? coeffs[j]·offset^j : 0   for j < N  (coset pre-scale + zero pad, G7)
