@@ -76,7 +76,7 @@ FP_HD fp fp_reduce_once(fp a) {
 
 // mont_mul(a, b) = a·b·2^-128 mod p, canonical result.  Requires b < p; a may be any 128-bit value.
 // [replaces field.rs:84-95 -> base.rs:94-151 + ruint div]
-FP_HD fp mont_mul(fp a, fp b) {
+FP_HD fp mont_mul_c(fp a, fp b) {
     uint32_t t[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = 0;
@@ -109,6 +109,109 @@ FP_HD fp mont_mul(fp a, fp b) {
     fp_u128 r = th - q;
     if (th < q) r += fp_prime_u128();
     return fp_from_u128(r);
+}
+// The same product on the device, laid out for gfx950's 64-bit multiply-add: v_mad_u64_u32 wants its 64-bit addend in an
+// even-aligned register pair, so the textbook row-by-row form above compiles with a v_mov for every "carry word into the low
+// half of a fresh pair" (36 v_mov in 106 VALU instructions).  Here the sixteen partial products accumulate in place in seven
+// 64-bit columns — E_k at words 2k,2k+1 for i+j even, O_k at words 2k+1,2k+2 for i+j odd — whose overflow bit is caught from
+// the instruction's own carry-out (one v_addc each), and the columns are merged by two 32-bit carry chains.  The 407·M of the
+// reduction is four independent products merged the same way.  71 VALU instructions, no v_mov (tools/mm_bench.hip checks
+// bit-equality with the C form and times both).  The assembler's hazard pass does not see inside an asm
+// statement, so the two wait states gfx950 wants between a VALU write of an SGPR carry and its VALU read are kept by instruction
+// order inside each statement (three instructions between every carry's write and its read); no carry crosses statements.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FP_MONT_MUL_C)
+__device__ __forceinline__ uint32_t fp_addc(uint32_t x, uint32_t y, uint32_t cin, uint32_t* cout) { return __builtin_addc(x, y, cin, cout); }
+__device__ __forceinline__ uint32_t fp_subc(uint32_t x, uint32_t y, uint32_t bin, uint32_t* bout) { return __builtin_subc(x, y, bin, bout); }
+__device__ __forceinline__ fp mont_mul_dev(fp a, fp b) {
+    // One asm statement per row a_i·b: its carries are made and used inside it, its accumulators go in and out as operands,
+    // so the compiler is free to retire a_i and finished columns between rows (one 25-instruction block held 27 registers
+    // at once and cost the NTT kernels three waves of occupancy).
+    uint64_t E0, E1, E2, E3, O0, O1, O2, c0, c1, c2;
+    uint32_t vE1, vE2, vO0, vO1, vO2, w1, w2;
+    asm("v_mad_u64_u32 %[E0], vcc, %[a], %[b0], 0\n\t"
+        "v_mad_u64_u32 %[O0], vcc, %[a], %[b1], 0\n\t"
+        "v_mad_u64_u32 %[E1], vcc, %[a], %[b2], 0\n\t"
+        "v_mad_u64_u32 %[O1], vcc, %[a], %[b3], 0\n\t"
+        : [E0] "=&v"(E0), [O0] "=&v"(O0), [E1] "=&v"(E1), [O1] "=&v"(O1)
+        : [a] "v"(a.w[0]), [b0] "v"(b.w[0]), [b1] "v"(b.w[1]), [b2] "v"(b.w[2]), [b3] "v"(b.w[3])
+        : "vcc");
+    asm("v_mad_u64_u32 %[O0], %[c0], %[a], %[b0], %[O0]\n\t"
+        "v_mad_u64_u32 %[E1], %[c1], %[a], %[b1], %[E1]\n\t"
+        "v_mad_u64_u32 %[O1], %[c2], %[a], %[b2], %[O1]\n\t"
+        "v_mad_u64_u32 %[E2], vcc, %[a], %[b3], 0\n\t"
+        "v_addc_co_u32_e64 %[vO0], vcc, 0, 0, %[c0]\n\t"
+        "v_addc_co_u32_e64 %[vE1], vcc, 0, 0, %[c1]\n\t"
+        "v_addc_co_u32_e64 %[vO1], vcc, 0, 0, %[c2]\n\t"
+        : [O0] "+v"(O0), [E1] "+v"(E1), [O1] "+v"(O1), [E2] "=&v"(E2), [vO0] "=&v"(vO0), [vE1] "=&v"(vE1), [vO1] "=&v"(vO1),
+          [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2)
+        : [a] "v"(a.w[1]), [b0] "v"(b.w[0]), [b1] "v"(b.w[1]), [b2] "v"(b.w[2]), [b3] "v"(b.w[3])
+        : "vcc");
+    asm("v_mad_u64_u32 %[E1], %[c0], %[a], %[b0], %[E1]\n\t"
+        "v_mad_u64_u32 %[O1], %[c1], %[a], %[b1], %[O1]\n\t"
+        "v_mad_u64_u32 %[E2], %[c2], %[a], %[b2], %[E2]\n\t"
+        "v_mad_u64_u32 %[O2], vcc, %[a], %[b3], 0\n\t"
+        "v_addc_co_u32_e64 %[vE1], vcc, 0, %[vE1], %[c0]\n\t"
+        "v_addc_co_u32_e64 %[vO1], vcc, 0, %[vO1], %[c1]\n\t"
+        "v_addc_co_u32_e64 %[vE2], vcc, 0, 0, %[c2]\n\t"
+        : [E1] "+v"(E1), [O1] "+v"(O1), [E2] "+v"(E2), [O2] "=&v"(O2), [vE1] "+v"(vE1), [vO1] "+v"(vO1), [vE2] "=&v"(vE2),
+          [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2)
+        : [a] "v"(a.w[2]), [b0] "v"(b.w[0]), [b1] "v"(b.w[1]), [b2] "v"(b.w[2]), [b3] "v"(b.w[3])
+        : "vcc");
+    asm("v_mad_u64_u32 %[O1], %[c0], %[a], %[b0], %[O1]\n\t"
+        "v_mad_u64_u32 %[E2], %[c1], %[a], %[b1], %[E2]\n\t"
+        "v_mad_u64_u32 %[O2], %[c2], %[a], %[b2], %[O2]\n\t"
+        "v_mad_u64_u32 %[E3], vcc, %[a], %[b3], 0\n\t"
+        "v_addc_co_u32_e64 %[vO1], vcc, 0, %[vO1], %[c0]\n\t"
+        "v_addc_co_u32_e64 %[vE2], vcc, 0, %[vE2], %[c1]\n\t"
+        "v_addc_co_u32_e64 %[vO2], vcc, 0, 0, %[c2]\n\t"
+        : [O1] "+v"(O1), [E2] "+v"(E2), [O2] "+v"(O2), [E3] "=&v"(E3), [vO1] "+v"(vO1), [vE2] "+v"(vE2), [vO2] "=&v"(vO2),
+          [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2)
+        : [a] "v"(a.w[3]), [b0] "v"(b.w[0]), [b1] "v"(b.w[1]), [b2] "v"(b.w[2]), [b3] "v"(b.w[3])
+        : "vcc");
+    (void)w1; (void)w2;
+    // T = E + (O << 32) + overflow words (vO0 at word 3, vE1 at 4, vO1 at 5, vE2 at 6, vO2 at 7)
+    uint32_t cy, t0, t1, t2, t3, t4, t5, t6, t7;
+    t0 = (uint32_t)E0;
+    t1 = fp_addc((uint32_t)(E0 >> 32), (uint32_t)O0, 0, &cy);
+    t2 = fp_addc((uint32_t)E1, (uint32_t)(O0 >> 32), cy, &cy);
+    t3 = fp_addc((uint32_t)(E1 >> 32), (uint32_t)O1, cy, &cy);
+    t4 = fp_addc((uint32_t)E2, (uint32_t)(O1 >> 32), cy, &cy);
+    t5 = fp_addc((uint32_t)(E2 >> 32), (uint32_t)O2, cy, &cy);
+    t6 = fp_addc((uint32_t)E3, (uint32_t)(O2 >> 32), cy, &cy);
+    t7 = (uint32_t)(E3 >> 32) + cy;
+    t3 = fp_addc(t3, vO0, 0, &cy);
+    t4 = fp_addc(t4, vE1, cy, &cy);
+    t5 = fp_addc(t5, vO1, cy, &cy);
+    t6 = fp_addc(t6, vE2, cy, &cy);
+    t7 = t7 + vO2 + cy;
+    // M = T_lo · p^-1 mod 2^128 = T_lo − ((T_lo·407 mod 2^9) << 119);  U = 407·M from four independent products
+    const uint64_t x0 = (uint64_t)t0 * 407u;
+    const uint32_t k9 = (uint32_t)x0 & 511u;
+    const uint32_t m3 = t3 - (k9 << 23);
+    const uint64_t x1 = (uint64_t)t1 * 407u, x2 = (uint64_t)t2 * 407u, x3 = (uint64_t)m3 * 407u;
+    uint32_t u0 = (uint32_t)x0, u1, u2, u3, u4;
+    u1 = fp_addc((uint32_t)(x0 >> 32), (uint32_t)x1, 0, &cy);
+    u2 = fp_addc((uint32_t)x2, (uint32_t)(x1 >> 32), cy, &cy);
+    u3 = fp_addc((uint32_t)(x2 >> 32), (uint32_t)x3, cy, &cy);
+    u4 = (uint32_t)(x3 >> 32) + cy;
+    // floor(M·p / 2^128) = (U >> 9) + carry,  carry = [ (M >> 119) + (U & 511) >= 512 ]
+    const uint32_t cq = ((m3 >> 23) + (u0 & 511u)) >> 9;
+    uint32_t q0 = __builtin_amdgcn_alignbit(u1, u0, 9), q1 = __builtin_amdgcn_alignbit(u2, u1, 9), q2 = __builtin_amdgcn_alignbit(u3, u2, 9), q3 = __builtin_amdgcn_alignbit(u4, u3, 9);
+    q0 = fp_addc(q0, cq, 0, &cy); q1 = fp_addc(q1, 0, cy, &cy); q2 = fp_addc(q2, 0, cy, &cy); q3 += cy;
+    uint32_t bw, r0, r1, r2, r3;
+    r0 = fp_subc(t4, q0, 0, &bw); r1 = fp_subc(t5, q1, bw, &bw); r2 = fp_subc(t6, q2, bw, &bw); r3 = fp_subc(t7, q3, bw, &bw);
+    // negative: add p = 1 + 0xcb800000·2^96
+    const uint32_t m = 0u - bw;                                   // all ones when negative
+    r0 = fp_addc(r0, m & 1u, 0, &cy); r1 = fp_addc(r1, 0, cy, &cy); r2 = fp_addc(r2, 0, cy, &cy); r3 = r3 + (m & FP_P3) + cy;
+    return fp_make(r0, r1, r2, r3);
+}
+#endif
+FP_HD fp mont_mul(fp a, fp b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FP_MONT_MUL_C)
+    return mont_mul_dev(a, b);
+#else
+    return mont_mul_c(a, b);
+#endif
 }
 FP_HD fp fp_to_mont(fp a) { return mont_mul(a, fp_mont_r2()); }             // a·R
 FP_HD fp fp_from_mont(fp a) { return mont_mul(a, fp_one()); }               // a·R^-1

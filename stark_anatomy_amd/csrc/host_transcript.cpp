@@ -199,11 +199,30 @@ inline size_t put_u128_dec(char* out, unsigned __int128 v) {               // se
     return n + put_u64_dec_padded19(out + n, l0);
 }
 // An item whose first byte is LAZY_PATH (no JSON text starts with it) still holds raw digests: write it out in place.
-const char LAZY_PATH = 0x01;
+const char LAZY_PATH = 0x01, LAZY_CODEWORD = 0x02, LAZY_LEAVES = 0x03;
 struct ByteDec { char txt[256][4]; uint8_t len[256]; ByteDec() { for (int v = 0; v < 256; ++v) { len[v] = (uint8_t)put_u64_dec(txt[v], (uint64_t)v); txt[v][len[v]] = ','; } } };
 const ByteDec BYTE_DEC;                                                   // "0," .. "255,": one 4-byte copy per value
+void materialize_elems(std::string& it, const char* head, size_t head_len) {      // {"Codeword":[dec,...]} / {"Leaves":[dec,...]}: u128 as bare decimals
+    const size_t n = (it.size() - 1) / 16;
+    std::string s(head_len + n * 40 + 2, '\0');
+    char* buf = &s[0];
+    size_t o = head_len;
+    memcpy(buf, head, head_len);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t w[2];
+        memcpy(w, it.data() + 1 + 16 * i, 16);
+        if (i) buf[o++] = ',';
+        o += put_u128_dec(buf + o, ((unsigned __int128)w[1] << 64) | w[0]);
+    }
+    buf[o++] = ']'; buf[o++] = '}';
+    s.resize(o);
+    it = std::move(s);
+}
 void materialize(std::string& it) {
-    if (it.empty() || it[0] != LAZY_PATH) return;
+    if (it.empty()) return;
+    if (it[0] == LAZY_CODEWORD) { materialize_elems(it, "{\"Codeword\":[", 13); return; }
+    if (it[0] == LAZY_LEAVES) { materialize_elems(it, "{\"Leaves\":[", 11); return; }
+    if (it[0] != LAZY_PATH) return;
     const size_t n = (it.size() - 1) / 64;
     const uint8_t* d = (const uint8_t*)it.data() + 1;
     std::string s(9 + n * (10 + 64 * 4 + 3) + 2 + 4, '\0');
@@ -347,7 +366,7 @@ int32_t sh_proofstream_free(sh_proofstream* ps) { delete ps; return SH_OK; }
 int32_t sh_proofstream_push_json(sh_proofstream* ps, const uint8_t* json, size_t len) {       // proof_stream.rs:25-27
     SH_GUARD_BEGIN
     if (!ps || (!json && len)) return sh_fail(SH_EINVAL, "sh_proofstream_push_json: null pointer");
-    if (len && json[0] == (uint8_t)LAZY_PATH) return sh_fail(SH_EINVAL, "sh_proofstream_push_json: not JSON text");   // the marker of a path kept in raw form
+    if (len && json[0] <= 0x03) return sh_fail(SH_EINVAL, "sh_proofstream_push_json: not JSON text");   // the marker of a path kept in raw form
     ps->items.emplace_back((const char*)json, len);
     return SH_OK;
     SH_GUARD_END("sh_proofstream_push_json")
@@ -367,16 +386,9 @@ int32_t sh_proofstream_push_merkle_root(sh_proofstream* ps, const uint8_t root[6
 int32_t sh_proofstream_push_codeword(sh_proofstream* ps, const uint64_t* elems, size_t n) {
     SH_GUARD_BEGIN
     if (!ps || (!elems && n)) return sh_fail(SH_EINVAL, "sh_proofstream_push_codeword: null pointer");
-    std::string s(13 + n * 40 + 2, '\0');
-    char* buf = &s[0];
-    size_t o = 13;
-    memcpy(buf, "{\"Codeword\":[", 13);
-    for (size_t i = 0; i < n; ++i) {
-        if (i) buf[o++] = ',';
-        o += put_u128_dec(buf + o, ((unsigned __int128)elems[2 * i + 1] << 64) | elems[2 * i]);
-    }
-    buf[o++] = ']'; buf[o++] = '}';
-    s.resize(o);
+    std::string s(1 + n * 16, '\0');                   // raw until read, like a path (see sh_proofstream_push_path)
+    s[0] = LAZY_CODEWORD;
+    if (n) memcpy(&s[1], elems, n * 16);
     ps->items.push_back(std::move(s));
     return SH_OK;
     SH_GUARD_END("sh_proofstream_push_codeword")
@@ -386,16 +398,9 @@ int32_t sh_proofstream_push_codeword(sh_proofstream* ps, const uint64_t* elems, 
 int32_t sh_proofstream_push_leaves(sh_proofstream* ps, const uint64_t* elems, size_t n) {
     SH_GUARD_BEGIN
     if (!ps || (!elems && n)) return sh_fail(SH_EINVAL, "sh_proofstream_push_leaves: null pointer");
-    std::string s(11 + n * 40 + 2, '\0');
-    char* buf = &s[0];
-    size_t o = 11;
-    memcpy(buf, "{\"Leaves\":[", 11);
-    for (size_t i = 0; i < n; ++i) {
-        if (i) buf[o++] = ',';
-        o += put_u128_dec(buf + o, ((unsigned __int128)elems[2 * i + 1] << 64) | elems[2 * i]);
-    }
-    buf[o++] = ']'; buf[o++] = '}';
-    s.resize(o);
+    std::string s(1 + n * 16, '\0');
+    s[0] = LAZY_LEAVES;
+    if (n) memcpy(&s[1], elems, n * 16);
     ps->items.push_back(std::move(s));
     return SH_OK;
     SH_GUARD_END("sh_proofstream_push_leaves")

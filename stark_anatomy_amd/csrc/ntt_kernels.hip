@@ -15,6 +15,11 @@
 // Butterflies are decimation-in-frequency, so rows come out bit-reversed and the reversal is
 // absorbed into the store address.  Twiddles come from a two-level table of Montgomery-form powers
 // (4096 + n/4096 entries, L2-resident): w^e = lo[e & 4095]·hi[e >> 12].
+// The NTT passes keep the plain-C mont_mul: the asm form (fp128.cuh) has a third fewer instructions but holds more registers at
+// once, k_ntt_pass goes from 64 to 79 VGPRs, and a 1024-lane workgroup then no longer fits twice on a CU — measured at 2^24:
+// 1.005 ms with the C form, 1.16 ms with the asm form, 1.14 ms with the asm form squeezed into 64 VGPRs by spilling
+// (profiles/r02_mont_mul_microbench.txt).
+#define FP_MONT_MUL_C
 #include "kernels.h"
 
 struct NttPassParams {
