@@ -165,6 +165,20 @@ int32_t sh_dev_fri_fold_range(sh_ctx* ctx, const uint64_t* d_lo, const uint64_t*
 /* d_data[i] *= base^(j0+i), i < count: the coset pre-scale (G7) of the slice [j0, j0+count) of a coefficient vector. */
 int32_t sh_dev_scale_powers(sh_ctx* ctx, uint64_t* d_data, size_t count, uint64_t j0, const uint64_t base[2]);
 
+/* ---------------- device-side pieces of the multi-GPU path (no counterpart in the reference) ----------------
+ * None of these synchronises or reads host memory except sh_dev_merkle_commit_pairs, which returns the round's root.
+ * sh_dev_transpose: d_out[c][r] = d_in[r][c], rows x cols elements — the pack of an all-to-all exchange (cols = P·b:
+ * d_out is then [dest s][col][row], contiguous per destination).  sh_dev_interleave_blocks: d_out[c][s][r] =
+ * d_in[s][c][r], (P, b, a) -> (b, P, a) — the unpack after it.  In and out must not alias. */
+int32_t sh_dev_zero(sh_ctx* ctx, void* dptr, size_t bytes);                          /* hipMemsetAsync on the context's stream */
+int32_t sh_dev_transpose(sh_ctx* ctx, const uint64_t* d_in, size_t rows, size_t cols, uint64_t* d_out);
+int32_t sh_dev_interleave_blocks(sh_ctx* ctx, const uint64_t* d_in, size_t P, size_t b, size_t a, uint64_t* d_out);
+/* Merkle root over leafhash(d_elems[0..L)) written to 64 bytes of DEVICE memory at d_root (a rank's sub-root of a sharded round). */
+int32_t sh_dev_merkle_root_elems(sh_ctx* ctx, const uint64_t* d_elems, size_t L, uint8_t* d_root);
+/* Root of the 2P-leaf tree over the all-gathered sub-roots of a sharded round: d_pairs = P x 2 digests, rank s's roots over
+ * half-slices s and P + s of the codeword; leaves in half-slice order.  P a power of two. */
+int32_t sh_dev_merkle_commit_pairs(sh_ctx* ctx, const uint8_t* d_pairs, size_t P, uint8_t root[64]);
+
 /* ---------------- FRI commit driver ----------------
  * for r in 0..R: root_r = merkle(leafhash(cw_r)); cb(root_r) -> alpha_r; cw_{r+1} = fold(cw_r).
  * R = sh_fri_num_rounds(N, expansion, num_colinearity_tests); the last round's codeword (length

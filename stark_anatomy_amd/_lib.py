@@ -77,6 +77,11 @@ _PROTOS = {
     "sh_twiddle_scale": (C.c_int32, [ctx_t, u64p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32]),
     "sh_dev_twiddle_scale": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32]),
     "sh_coset_lde": (C.c_int32, [ctx_t, u64p, C.c_uint32, C.c_uint32, u64p, u64p]),
+    "sh_dev_zero": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t]),
+    "sh_dev_transpose": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "sh_dev_interleave_blocks": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "sh_dev_merkle_root_elems": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sh_dev_merkle_commit_pairs": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, u8p]),
     "sh_poly_mul": (C.c_int32, [ctx_t, u64p, C.c_size_t, u64p, C.c_size_t, u64p]),
     "sh_dev_poly_mul": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sh_coset_zerofier_div": (C.c_int32, [ctx_t, u64p, C.c_uint32, C.c_uint32, u64p, u64p, u64p]),

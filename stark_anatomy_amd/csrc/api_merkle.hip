@@ -153,27 +153,61 @@ int32_t sh_merkle_commit_elems(sh_ctx* c, const uint64_t* elems, size_t L, uint8
     HIPCHK(hipMemcpyAsync(d, elems, L * 16, hipMemcpyHostToDevice, c->stream));
     return sh_dev_merkle_commit_elems(c, (const uint64_t*)d, L, root);
 }
-// MerkleTree::open, merkle.rs:70-108.  All levels are built once on the GPU (level by level, K = 1) and the
-// log2(L) siblings are gathered from them, instead of the reference's per-call subtree re-commits.
+// MerkleTree::open, merkle.rs:70-108: one index through the batched path (api_query.hip).
 int32_t sh_merkle_open(sh_ctx* c, const uint8_t* leaves, size_t L, size_t index, uint8_t* path, size_t* path_len) {
     CTXCHK(c);
     if (!leaves || !path || !path_len) return sh_fail(SH_EINVAL, "sh_merkle_open: null pointer");
     if (!is_pow2(L)) return sh_fail(SH_EINVAL, "sh_merkle_open: leaf count must be a power of two (merkle.rs:72)");
     if (index >= L) return sh_fail(SH_EBOUNDS, "sh_merkle_open: index out of bounds (merkle.rs:75)");
     if (L < 2) return sh_fail(SH_EBOUNDS, "sh_merkle_open: a one-leaf tree has no path (merkle.rs:104)");
-    const uint32_t depth = ilog2(L);
-    void* d;                                   // levels 0..depth-1 back to back: L + L/2 + ... + 2 digests
-    SHCHK(ensure_scratch(c, SCR_IO_A, 2 * L * 64, &d));
-    digest64* lvl = (digest64*)d;
-    HIPCHK(hipMemcpyAsync(lvl, leaves, L * 64, hipMemcpyHostToDevice, c->stream));
-    size_t n = L, idx = index;
-    for (uint32_t l = 0; l < depth; ++l) {
-        HIPCHK(hipMemcpyAsync(path + 64 * (size_t)l, lvl + (idx ^ 1), 64, hipMemcpyDeviceToHost, c->stream));
-        if (l + 1 < depth) HIPCHK(launch_node_subtree(lvl, lvl + n, n >> 1, 1, c->stream));
-        lvl += n; n >>= 1; idx >>= 1;
-    }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    *path_len = depth;
+    const uint64_t idx = index;
+    SHCHK(sh_merkle_open_batch(c, leaves, L, &idx, 1, path));
+    *path_len = ilog2(L);
+    return SH_OK;
+}
+
+// ---- device-resident pieces of a sharded commit: nothing here synchronises or touches the host
+// root of merkle(leafhash(d_elems[0..L))) -> 64 bytes at d_root
+int32_t sh_dev_merkle_root_elems(sh_ctx* c, const uint64_t* d_elems, size_t L, uint8_t* d_root) {
+    CTXCHK(c);
+    if (!d_elems || !d_root) return sh_fail(SH_EINVAL, "sh_dev_merkle_root_elems: null pointer");
+    if (!is_pow2(L)) return sh_fail(SH_EINVAL, "sh_dev_merkle_root_elems: element count must be a power of two (merkle.rs:36)");
+    SHCHK(merkle_root_from_elems(c, (const fp*)d_elems, L));
+    c->mail_pending = false;                                       // nobody waits for this root on the host
+    HIPCHK(hipMemcpyAsync(d_root, c->d_root, 64, hipMemcpyDeviceToDevice, c->stream));
+    return SH_OK;
+}
+// root of the 2P-leaf tree over the all-gathered sub-root pairs of a sharded round: d_pairs = (P, 2) digests, rank s's
+// roots over half-slices s and P + s; leaf order = half-slice order.  One host touch: the root.
+int32_t sh_dev_merkle_commit_pairs(sh_ctx* c, const uint8_t* d_pairs, size_t P, uint8_t root[64]) {
+    CTXCHK(c);
+    if (!d_pairs || !root) return sh_fail(SH_EINVAL, "sh_dev_merkle_commit_pairs: null pointer");
+    if (!is_pow2(P) || P > ((size_t)1 << 20)) return sh_fail(SH_EINVAL, "sh_dev_merkle_commit_pairs: rank count must be a power of two");
+    void* lv;
+    SHCHK(ensure_scratch(c, SCR_ROOTS, 2 * P * sizeof(digest64), &lv));
+    HIPCHK(launch_pair_leaves((const digest64*)d_pairs, (digest64*)lv, P, c->stream));
+    SHCHK(reduce_digests(c, (const digest64*)lv, 2 * P));
+    return fetch_root(c, root);
+}
+int32_t sh_dev_zero(sh_ctx* c, void* d, size_t bytes) {
+    CTXCHK(c);
+    if (!bytes) return SH_OK;
+    if (!d) return sh_fail(SH_EINVAL, "sh_dev_zero: null pointer");
+    HIPCHK(hipMemsetAsync(d, 0, bytes, c->stream));
+    return SH_OK;
+}
+int32_t sh_dev_transpose(sh_ctx* c, const uint64_t* d_in, size_t rows, size_t cols, uint64_t* d_out) {
+    CTXCHK(c);
+    if (!rows || !cols) return SH_OK;
+    if (!d_in || !d_out || d_in == d_out) return sh_fail(SH_EINVAL, "sh_dev_transpose: null or aliased pointer");
+    HIPCHK(launch_transpose16((const fp*)d_in, (fp*)d_out, rows, cols, c->stream));
+    return SH_OK;
+}
+int32_t sh_dev_interleave_blocks(sh_ctx* c, const uint64_t* d_in, size_t P, size_t b, size_t a, uint64_t* d_out) {
+    CTXCHK(c);
+    if (!P || !b || !a) return SH_OK;
+    if (!d_in || !d_out || d_in == d_out) return sh_fail(SH_EINVAL, "sh_dev_interleave_blocks: null or aliased pointer");
+    HIPCHK(launch_interleave_blocks((const fp*)d_in, (fp*)d_out, P, b, a, c->stream));
     return SH_OK;
 }
 

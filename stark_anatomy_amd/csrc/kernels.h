@@ -12,6 +12,13 @@ enum { FPOP_ADD = 0, FPOP_SUB = 1, FPOP_MUL = 2, FPOP_DIV = 3, FPOP_INV = 4, FPO
 // inversion, one field inversion per 2048 elements).  FPOP_INV_MONT: out = 2^128 / a, the factor that makes
 // mont_mul(x, out) = x / a.
 hipError_t launch_fp_binop(int op, const fp* a, const fp* b, fp* out, size_t n, uint32_t* d_flag, hipStream_t s);
+// ---- dist_kernels.hip (multi-GPU data movement) ----
+// out[c][r] = in[r][c], rows x cols elements (the pack of an all-to-all exchange when cols = P·b)
+hipError_t launch_transpose16(const fp* in, fp* out, size_t rows, size_t cols, hipStream_t s);
+// out[c][s][r] = in[s][c][r], (P, b, a) -> (b, P, a): the unpack after the exchange
+hipError_t launch_interleave_blocks(const fp* in, fp* out, size_t P, size_t b, size_t a, hipStream_t s);
+// leaves[i] = pairs[i][0], leaves[P + i] = pairs[i][1]
+hipError_t launch_pair_leaves(const digest64* pairs, digest64* leaves, size_t P, hipStream_t s);
 // ---- query_kernels.hip ----
 // One tree of a proof's query phase: the codeword under it, the digest arrays its commit left in memory (level[k] = log2
 // of the leaves under one digest of stored[k], ascending, all < log_L), and where its indices / workgroups / paths sit.

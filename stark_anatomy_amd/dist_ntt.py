@@ -113,21 +113,50 @@ class GpuEngine:
         self._chk(lib.sh_dev_scale_powers(self.ctx.handle, t.data_ptr(), t.numel() // 2, j0, p))
         return t
 
-    def subroot(self, t):
-        """Merkle root over the leaf hashes of the elements of `t` (a power-of-two count)."""
+    def zeros(self, m):
+        """(m, 2) elements of zeros (hipMemsetAsync, no fill kernel)"""
         from ._lib import lib
-        from .context import _u8p
-        assert t.is_contiguous()
-        root = np.zeros(64, dtype=np.uint8)
-        self._chk(lib.sh_dev_merkle_commit_elems(self.ctx.handle, t.data_ptr(), t.numel() // 2, _u8p(root)))
-        return root.tobytes()
+        with self.scope():
+            t = self.torch.empty((m, 2), dtype=self.torch.int64, device=self.device)
+        self._chk(lib.sh_dev_zero(self.ctx.handle, t.data_ptr(), m * 16))
+        return t
 
-    def top_root(self, digests):
+    def transpose(self, x):
+        """x: (rows, cols, 2) contiguous -> (cols, rows, 2): the pack of an exchange (k_transpose16, LDS tiles)"""
+        from ._lib import lib
+        assert x.is_contiguous() and x.dim() == 3
+        rows, cols = x.shape[0], x.shape[1]
+        with self.scope():
+            out = self.torch.empty((cols, rows, 2), dtype=x.dtype, device=x.device)
+        self._chk(lib.sh_dev_transpose(self.ctx.handle, x.data_ptr(), rows, cols, out.data_ptr()))
+        return out
+
+    def interleave(self, recv, P, b, a):
+        """recv: [src s][col c][row r] -> (b, P·a, 2) = [c][s][r]: the unpack after an exchange (k_interleave_blocks)"""
+        from ._lib import lib
+        assert recv.is_contiguous() and recv.numel() == 2 * P * b * a
+        with self.scope():
+            out = self.torch.empty((b, P * a, 2), dtype=recv.dtype, device=recv.device)
+        self._chk(lib.sh_dev_interleave_blocks(self.ctx.handle, recv.data_ptr(), P, b, a, out.data_ptr()))
+        return out
+
+    def subroot_pair(self, lo, hi):
+        """Merkle roots over the leaf hashes of `lo` and of `hi` -> 128 bytes that stay on the device (no synchronise)."""
+        from ._lib import lib
+        assert lo.is_contiguous() and hi.is_contiguous()
+        with self.scope():
+            pair = self.torch.empty(128, dtype=self.torch.uint8, device=self.device)
+        self._chk(lib.sh_dev_merkle_root_elems(self.ctx.handle, lo.data_ptr(), lo.numel() // 2, pair.data_ptr()))
+        self._chk(lib.sh_dev_merkle_root_elems(self.ctx.handle, hi.data_ptr(), hi.numel() // 2, pair.data_ptr() + 64))
+        return pair
+
+    def top_root_pairs(self, pairs, P):
+        """pairs: the all-gathered (P, 2, 64) sub-roots on the device -> the round's root (the round's one host touch)"""
         from ._lib import lib
         from .context import _u8p
-        arr = np.frombuffer(b"".join(digests), dtype=np.uint8).copy()
+        assert pairs.is_contiguous() and pairs.numel() == 128 * P
         root = np.zeros(64, dtype=np.uint8)
-        self._chk(lib.sh_merkle_commit(self.ctx.handle, _u8p(arr), len(digests), _u8p(root)))
+        self._chk(lib.sh_dev_merkle_commit_pairs(self.ctx.handle, pairs.data_ptr(), P, _u8p(root)))
         return root.tobytes()
 
     def fold_range(self, lo, hi, i0, alpha, offset, omega):
@@ -181,33 +210,37 @@ def _all_to_all(send, group):
     return recv
 
 
-def exchange_transpose(x, group=None):
+def exchange_transpose(x, engine, group=None):
     """The global matrix is (P·a) × (P·b) elements, row-major, rank r holding rows [r·a, (r+1)·a) as x of shape
-    (a, P·b, 2).  Returns this rank's columns [r·b, (r+1)·b) as rows: shape (b, P·a, 2)."""
+    (a, P·b, 2).  Returns this rank's columns [r·b, (r+1)·b) as rows: shape (b, P·a, 2).
+    Pack = the local transpose (its rows [s·b, (s+1)·b) are what rank s gets), unpack = swap of the two outer indices
+    of what arrives; both are the engine's kernels, torch only carries the buffers through the collective."""
     P, _ = _world_rank(group)
     a, cols = x.shape[0], x.shape[1]
     assert cols % P == 0, "column count must be divisible by the number of ranks"
     b = cols // P
+    send = engine.transpose(x.contiguous())                           # (P·b, a, 2) == [dest s][col c][row]
     if P == 1:
-        return x.transpose(0, 1).contiguous()
-    send = x.view(a, P, b, 2).permute(1, 2, 0, 3).contiguous()       # [dest s][col c][row]
-    recv = _all_to_all(send, group)                                   # [src s][col c][row of s]
-    return recv.permute(1, 0, 2, 3).reshape(b, P * a, 2).contiguous()
+        return send
+    recv = _all_to_all(send.view(P, b, a, 2), group)                  # [src s][col c][row of s]
+    return engine.interleave(recv, P, b, a)
 
 
-def _all_gather_bytes(b, group, device):
+def _all_gather_pairs(pair, group):
+    """pair: 128 bytes on the engine's device -> (P·128,) bytes, rank order, on the same device (one tiny collective)."""
     import torch
     dist = _dist()
     P, _ = _world_rank(group)
     if P == 1:
-        return [b]
-    stage = device.type == "cuda" and dist.get_backend(group) != "nccl"
-    dev = torch.device("cpu") if stage else device
-    t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
-    out = torch.empty(P * len(b), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(out, t, group=group)
-    raw = out.cpu().numpy().tobytes()
-    return [raw[i * len(b):(i + 1) * len(b)] for i in range(P)]
+        return pair
+    if _needs_staging(pair, group):
+        s = pair.cpu()
+        out = torch.empty(P * 128, dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, s, group=group)
+        return out.to(pair.device)
+    out = torch.empty(P * 128, dtype=torch.uint8, device=pair.device)
+    dist.all_gather_into_tensor(out, pair, group=group)
+    return out
 
 
 def all_gather_slices(x, group=None):
@@ -283,20 +316,20 @@ def dist_ntt(local, log_n, engine, group=None, inverse=False, input_layout="natu
         raise ValueError("local slice has the wrong length")
     with engine.scope():
         if input_layout == "natural":
-            y = exchange_transpose(local.reshape(n1 // P, n2, 2), group)        # (n2/P, n1, 2): [j2l][j1]
+            y = exchange_transpose(local.reshape(n1 // P, n2, 2), engine, group)  # (n2/P, n1, 2): [j2l][j1]
         elif input_layout == "columns":
             y = local.reshape(n2 // P, n1, 2).contiguous()
         else:
             raise ValueError(input_layout)
         engine.ntt_rows(y, l1, inverse)                                          # [j2l][k1]
         engine.twiddle(y, l1, g * (n2 // P), 0, log_n, inverse)
-        z = exchange_transpose(y, group)                                         # (n1/P, n2, 2): [k1l][j2]
+        z = exchange_transpose(y, engine, group)                                 # (n1/P, n2, 2): [k1l][j2]
         engine.ntt_rows(z, l2, inverse)                                          # [k1l][k2] = X[k1 + n1·k2]
         if output_layout == "rows":
             return z
         if output_layout != "natural":
             raise ValueError(output_layout)
-        return exchange_transpose(z, group).reshape(-1, 2)                       # [k2l][k1] = natural slice
+        return exchange_transpose(z, engine, group).reshape(-1, 2)               # [k2l][k1] = natural slice
 
 
 def dist_coset_lde(local_coeffs, log_n, log_expansion, offset, engine, group=None):
@@ -311,13 +344,38 @@ def dist_coset_lde(local_coeffs, log_n, log_expansion, offset, engine, group=Non
         raise ValueError("local coefficient slice has the wrong length")
     with engine.scope():
         scaled = engine.scale_powers(local_coeffs.reshape(-1, 2).clone(), g * m_in, offset)
-        # padded vector = [coeffs | zeros]; rank g owns padded[g·m_out, (g+1)·m_out): gather the coefficient slices
-        # that fall in it (they come from ranks g·2^e … only when g < P/2^e; others own zeros).
-        full = all_gather_slices(scaled, group) if P > 1 else scaled
-        mine = torch.zeros((m_out, 2), dtype=scaled.dtype, device=scaled.device)
-        lo, hi = g * m_out, min((g + 1) * m_out, n)
-        if lo < n:
-            mine[: hi - lo] = full[lo:hi]
+        # padded vector = [coeffs | zeros]; rank g owns padded[g·m_out, (g+1)·m_out), m_out = 2^e·m_in: the coefficient slice
+        # of rank s lands on rank s >> e at offset (s mod 2^e)·m_in.  Only those slices move, point to point; ranks
+        # >= P/2^e own zeros only.
+        mine = engine.zeros(m_out)
+        E = 1 << log_expansion
+        dst = g // E
+        if P == 1:
+            mine[:m_in] = scaled
+        else:
+            dist = _dist()
+            stage = _needs_staging(scaled, group)
+            gr = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+            ops, landed = [], []
+            if dst == g:
+                mine[(g % E) * m_in:(g % E + 1) * m_in] = scaled
+            else:
+                buf = scaled.cpu() if stage else scaled
+                landed.append((None, buf))
+                ops.append(dist.P2POp(dist.isend, buf, gr(dst), group=group))
+            for s_ in range(g * E, min((g + 1) * E, P)):
+                if s_ == g:
+                    continue
+                view = mine[(s_ % E) * m_in:(s_ % E + 1) * m_in]
+                buf = torch.empty((m_in, 2), dtype=scaled.dtype) if stage else view
+                landed.append((view if stage else None, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, gr(s_), group=group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            for view, buf in landed:
+                if view is not None:
+                    view.copy_(buf)
     return dist_ntt(mine, log_n + log_expansion, engine, group)
 
 
@@ -350,9 +408,8 @@ def dist_fri_commit(local, N, engine, offset, expansion_factor=4, num_colinearit
     with engine.scope():
         while L // (2 * P) >= max(1, min_half) and _num_rounds(L, expansion_factor, num_colinearity_tests) > 1:
             lo, hi = _regroup(chunk, group)
-            pair = engine.subroot(lo) + engine.subroot(hi)
-            subs = _all_gather_bytes(pair, group, chunk.device)
-            root = engine.top_root([s[:64] for s in subs] + [s[64:] for s in subs])
+            pairs = _all_gather_pairs(engine.subroot_pair(lo, hi), group)     # sub-roots never leave the device
+            root = engine.top_root_pairs(pairs, P)                            # the round's one host touch
             roots.append(root)
             alpha = engine.push_root_and_sample(ps, root)
             log_L = L.bit_length() - 1

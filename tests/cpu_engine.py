@@ -51,11 +51,23 @@ class OracleEngine:
         vals = co.to_ints(_np(t))
         return _put(t, co.to_arr([po.fp_mul(v, pow(int(base), j0 + i, po.P)) for i, v in enumerate(vals)]))
 
-    def subroot(self, t):
-        return co.merkle_commit_elems(_np(t))
+    def zeros(self, m):
+        return torch.zeros((m, 2), dtype=torch.int64)
 
-    def top_root(self, digests):
-        return po.merkle_commit(list(digests))
+    def transpose(self, x):
+        return x.transpose(0, 1).contiguous()
+
+    def interleave(self, recv, P, b, a):
+        return recv.reshape(P, b, a, 2).permute(1, 0, 2, 3).reshape(b, P * a, 2).contiguous()
+
+    def subroot_pair(self, lo, hi):
+        raw = co.merkle_commit_elems(_np(lo)) + co.merkle_commit_elems(_np(hi))
+        return torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+
+    def top_root_pairs(self, pairs, P):
+        raw = pairs.numpy().tobytes()
+        subs = [raw[128 * s:128 * (s + 1)] for s in range(P)]
+        return po.merkle_commit([s[:64] for s in subs] + [s[64:] for s in subs])
 
     def fold_range(self, lo, hi, i0, alpha, offset, omega):
         x, y = co.to_ints(_np(lo)), co.to_ints(_np(hi))

@@ -113,5 +113,7 @@ def test_dist_ntt_lde_fri_match_oracle(tmp_path, world, log_n, t, min_half):
 def test_exchange_transpose_single_process():
     import torch
     from stark_anatomy_amd.dist_ntt import exchange_transpose
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cpu_engine import OracleEngine
     x = torch.arange(3 * 8 * 2, dtype=torch.int64).reshape(3, 8, 2)
-    assert torch.equal(exchange_transpose(x), x.transpose(0, 1).contiguous())
+    assert torch.equal(exchange_transpose(x, OracleEngine()), x.transpose(0, 1).contiguous())

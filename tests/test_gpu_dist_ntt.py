@@ -94,10 +94,45 @@ def engine():
     return GpuEngine(0)
 
 
-@pytest.mark.parametrize("log_n", [2, 9, 16, 20])
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 8), (32, 32), (33, 65), (100, 7), (1024, 4096), (4096, 513)])
+def test_transpose_and_interleave_kernels(ctx, rows, cols):
+    """the pack / unpack kernels of an all-to-all exchange (sh_dev_transpose, sh_dev_interleave_blocks) against numpy"""
+    x = co.splitmix_elems(rows * 31 + cols, rows * cols)
+    d_in, d_out = ctx.alloc(rows * cols * 16).upload(x), ctx.alloc(rows * cols * 16)
+    _lib.check(_lib.lib.sh_dev_transpose(ctx.handle, d_in.ptr, rows, cols, d_out.ptr))
+    assert np.array_equal(d_out.download(np.uint64, (cols, rows, 2)), x.reshape(rows, cols, 2).transpose(1, 0, 2))
+    for Pn in (1, 2, 4):
+        if cols % Pn:
+            continue
+        b, a = cols // Pn, rows                                        # in = [s][c][r] -> out = [c][s][r]
+        _lib.check(_lib.lib.sh_dev_interleave_blocks(ctx.handle, d_in.ptr, Pn, b, a, d_out.ptr))
+        assert np.array_equal(d_out.download(np.uint64, (b, Pn, a, 2)), x.reshape(Pn, b, a, 2).transpose(1, 0, 2, 3))
+    assert _lib.lib.sh_dev_transpose(ctx.handle, d_in.ptr, rows, cols, d_in.ptr) == _lib.SH_EINVAL      # no aliasing
+    d_in.free(); d_out.free()
+
+
+def test_pair_roots_stay_on_device(ctx):
+    """sh_dev_merkle_root_elems + sh_dev_merkle_commit_pairs (a sharded round's sub-roots and top tree) == one tree over
+    the whole codeword: P = 4 ranks' half-slices s and P + s."""
+    Pn, h = 4, 1 << 10
+    cw = co.splitmix_elems(77, 2 * Pn * h)
+    d_cw = ctx.alloc(cw.nbytes).upload(cw)
+    d_pairs = ctx.alloc(128 * Pn)
+    for s in range(Pn):
+        _lib.check(_lib.lib.sh_dev_merkle_root_elems(ctx.handle, d_cw.ptr + 16 * s * h, h, d_pairs.ptr + 128 * s))
+        _lib.check(_lib.lib.sh_dev_merkle_root_elems(ctx.handle, d_cw.ptr + 16 * (Pn + s) * h, h, d_pairs.ptr + 128 * s + 64))
+    root = np.zeros(64, dtype=np.uint8)
+    from stark_anatomy_amd.context import _u8p
+    _lib.check(_lib.lib.sh_dev_merkle_commit_pairs(ctx.handle, d_pairs.ptr, Pn, _u8p(root)))
+    assert root.tobytes() == co.merkle_commit_elems(cw)
+    assert _lib.lib.sh_dev_merkle_commit_pairs(ctx.handle, d_pairs.ptr, 3, _u8p(root)) == _lib.SH_EINVAL
+    d_cw.free(); d_pairs.free()
+
+
+@pytest.mark.parametrize("log_n", [2, 9, 16, 20, 24])
 def test_four_step_single_rank(engine, log_n):
-    """P = 1: the four-step decomposition (batched column NTTs, twiddle, batched row NTTs, torch transposes) equals the
-    direct transform; at 2^20 against the library's own one-shot NTT, below that against the oracle."""
+    """P = 1: the four-step decomposition (batched column NTTs, twiddle, batched row NTTs, transposes by k_transpose16)
+    equals the direct transform; from 2^20 against the library's own one-shot NTT, below that against the oracle."""
     from stark_anatomy_amd import dist_ntt as dn
     n = 1 << log_n
     x = co.splitmix_elems(31 + log_n, n)
@@ -151,8 +186,10 @@ if g == 0:
 '''
 
 
-def test_two_ranks_one_gpu_gloo(tmp_path):
-    log_n = 14
+@pytest.mark.parametrize("log_n", [14, 22])
+def test_two_ranks_one_gpu_gloo(tmp_path, log_n):
+    """14: against the oracle.  22 (config 5's shape at a size two ranks on one card finish in seconds): against the
+    single-GPU NTT / LDE / commit of the product, which are themselves oracle-checked at that size."""
     n = 1 << log_n
     x = co.splitmix_elems(99, n)
     np.save(tmp_path / "in.npy", x)
@@ -166,10 +203,19 @@ def test_two_ranks_one_gpu_gloo(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     parts = pickle.load(open(out, "rb"))
-    assert np.array_equal(np.concatenate([p["ntt"] for p in parts]), co.ntt(x))
-    exp_cw = co.coset_lde(x[: n // 4], 2, G)
+    if log_n <= 16:
+        exp_ntt, exp_cw = co.ntt(x), co.coset_lde(x[: n // 4], 2, G)
+        r0, _, l0, ps0 = co.fri_commit(exp_cw, 4, 17, G)
+        ser0 = ps0.serialize()
+    else:
+        c1 = sa.Context(0)
+        exp_ntt, exp_cw = sa.ntt(x, ctx=c1), sa.coset_lde(x[: n // 4], 2, G, ctx=c1)
+        ps1 = sa.ProofStream()
+        roots1, l0 = sa.Fri(G, None, n, 4, 17, ctx=c1).commit(exp_cw, ps1)
+        r0, ser0 = [h.as_bytes() for h in roots1], ps1.serialize()
+        c1.close()
+    assert np.array_equal(np.concatenate([p["ntt"] for p in parts]), exp_ntt)
     assert np.array_equal(np.concatenate([p["lde"] for p in parts]), exp_cw)
-    r0, _, l0, ps0 = co.fri_commit(exp_cw, 4, 17, G)
     for p in parts:
         roots, last, s = p["fri"]
-        assert [bytes(a) for a in roots] == r0 and np.array_equal(last, l0) and s == ps0.serialize()
+        assert [bytes(a) for a in roots] == r0 and np.array_equal(last, l0) and s == ser0
