@@ -271,6 +271,35 @@ inline std::vector<FieldElement> coset_lde(const std::vector<FieldElement>& coef
     return from_words(out.data(), coeffs.size() << log_expansion);
 }
 
+// ------------------------------------------------------------------ polynomial layer
+// coefficients lowest degree first, never trimmed; no counterpart in the crate
+inline std::vector<FieldElement> poly_mul(const std::vector<FieldElement>& a, const std::vector<FieldElement>& b, Gpu& gpu = Gpu::default_gpu()) {
+    if (a.empty() || b.empty()) throw Panic("poly_mul: a polynomial needs at least one coefficient");
+    auto wa = to_words(a), wb = to_words(b);
+    std::vector<uint64_t> out(2 * (a.size() + b.size() - 1));
+    check(sh_poly_mul(gpu.raw(), wa.data(), a.size(), wb.data(), b.size(), out.data()), "sh_poly_mul");
+    return from_words(out.data(), a.size() + b.size() - 1);
+}
+// codeword[i] / ((offset·w_N^i)^(2^log_n) - c); panics like field.rs:101-103 when the coset meets a root of the zerofier
+inline std::vector<FieldElement> coset_zerofier_div(const std::vector<FieldElement>& codeword, uint32_t log_n, FieldElement c, FieldElement offset, Gpu& gpu = Gpu::default_gpu()) {
+    auto w = to_words(codeword);
+    std::vector<uint64_t> out(w.size());
+    uint64_t off[2] = {(uint64_t)offset.value(), (uint64_t)(offset.value() >> 64)}, cc[2] = {(uint64_t)c.value(), (uint64_t)(c.value() >> 64)};
+    const int32_t rc = sh_coset_zerofier_div(gpu.raw(), w.data(), log2_exact(codeword.size(), "coset_zerofier_div"), log_n, off, cc, out.data());
+    if (rc == SH_EDIVZERO) throw Panic("Cannot divide by zero");
+    check(rc, "sh_coset_zerofier_div");
+    return from_words(out.data(), codeword.size());
+}
+// (q, r) with f = q·(X^n - c) + r, deg r < n
+inline std::pair<std::vector<FieldElement>, std::vector<FieldElement>> poly_divmod_zerofier(const std::vector<FieldElement>& f, size_t n, FieldElement c, Gpu& gpu = Gpu::default_gpu()) {
+    auto w = to_words(f);
+    const size_t nq = f.size() > n ? f.size() - n : 0;
+    std::vector<uint64_t> q(2 * (nq ? nq : 1)), r(2 * n);
+    uint64_t cc[2] = {(uint64_t)c.value(), (uint64_t)(c.value() >> 64)};
+    check(sh_poly_divmod_zerofier(gpu.raw(), w.data(), f.size(), n, cc, nq ? q.data() : nullptr, r.data()), "sh_poly_divmod_zerofier");
+    return {from_words(q.data(), nq), from_words(r.data(), n)};
+}
+
 // enum ProofItem { MerkleRoot(MerkleHash), Codeword(Vec<u128>), Leaves(Vec<u128>), Path(Vec<MerkleHash>) } (G6, G9), kept
 // as the compact JSON serde's externally tagged representation gives it.
 inline std::string u128_dec(u128 v) {
