@@ -31,6 +31,8 @@
 #define BFI_I(i) "v_bfi_b32 %" #i ", %" #i ", %8, %8\n"
 #define XOR3_I(i) "v_or3_b32 %" #i ", %" #i ", %8, %8\n"
 #define LSHLOR_I(i) "v_lshl_or_b32 %" #i ", %" #i ", 3, %8\n"
+#define PACK_I(i) "v_pack_b32_f16 %" #i ", %" #i ", %8 op_sel:[1,0,0]\n"
+#define CNDMASK_I(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
 #define FMAC_I(i) "v_fmac_f32 %" #i ", %8, %8\n"
 #define LSHR_I(i) "v_lshrrev_b32 %" #i ", 7, %" #i "\n"
 
@@ -56,6 +58,8 @@ __global__ __launch_bounds__(256) void k32(uint32_t* out, int iters, uint32_t se
         if (KIND == 15) asm volatile(BLOCK(LSHLOR_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
         if (KIND == 16) asm volatile(BLOCK(FMAC_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
         if (KIND == 17) asm volatile(BLOCK(LSHR_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 18) asm volatile(BLOCK(PACK_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 19) asm volatile(BLOCK(CNDMASK_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
         if (KIND == 8) asm volatile(BLOCK(ADDCOP_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
@@ -97,12 +101,40 @@ static double time_ms(F launch) {
     return ms;
 }
 
+__global__ void k_pack_check(const uint32_t* in, uint32_t* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lo = in[2 * i], hi = in[2 * i + 1], r0, r1;
+    asm volatile("v_pack_b32_f16 %0, %2, %3 op_sel:[1,0,0]\nv_pack_b32_f16 %1, %3, %2 op_sel:[1,0,0]\n" : "=&v"(r0), "=&v"(r1) : "v"(lo), "v"(hi));
+    out[2 * i] = r0; out[2 * i + 1] = r1;                  // expected: the 64-bit value hi:lo rotated right by 16
+}
+static int pack_check() {
+    const int n = 1 << 16;
+    std::vector<uint32_t> h(2 * n), o(2 * n);
+    uint64_t s = 12345;
+    for (int i = 0; i < 2 * n; ++i) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; h[i] = (uint32_t)(s >> 32); }
+    const uint32_t nasty[] = {0x7c017c01u, 0xfc01fc01u, 0x00010001u, 0x80018001u, 0x7e007e00u, 0x7fffffffu, 0x0001fc01u, 0xffffffffu};   // sNaN, denormal, qNaN halves
+    for (int i = 0; i < 64; ++i) h[i] = nasty[i % 8];
+    uint32_t *di, *dout;
+    CHK(hipMalloc(&di, 8 * n)); CHK(hipMalloc(&dout, 8 * n));
+    CHK(hipMemcpy(di, h.data(), 8 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_pack_check, dim3(n / 256), dim3(256), 0, 0, di, dout, n);
+    CHK(hipMemcpy(o.data(), dout, 8 * n, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        const uint64_t v = ((uint64_t)h[2 * i + 1] << 32) | h[2 * i], r = (v >> 16) | (v << 48);
+        if (o[2 * i] != (uint32_t)r || o[2 * i + 1] != (uint32_t)(r >> 32)) ++bad;
+    }
+    printf("v_pack_b32_f16 op_sel:[1,0,0] pair as a 64-bit rotate right by 16: %d of %d differ (sNaN / denormal halves included)\n", bad, n);
+    return bad;
+}
 int main() {
+    pack_check();
     const int iters = 4000;
     void* buf;
     CHK(hipMalloc(&buf, (size_t)256 * 8 * 4 * 256 * 8));
     const char* n32[] = {"v_xor_b32", "v_add_u32", "v_alignbit_b32", "v_alignbyte_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_add3_u32", "v_xad_u32", "add_co+addc (x2 instr)",
-                         "v_xor_b32_e64 (VOP3 enc)", "v_add_u32_e64 (VOP3 enc)", "v_fma_f32 (VOP3)", "v_perm_b32", "v_bfi_b32", "v_or3_b32", "v_lshl_or_b32", "v_fmac_f32 (VOP2)", "v_lshrrev_b32 (VOP2)"};
+                         "v_xor_b32_e64 (VOP3 enc)", "v_add_u32_e64 (VOP3 enc)", "v_fma_f32 (VOP3)", "v_perm_b32", "v_bfi_b32", "v_or3_b32", "v_lshl_or_b32", "v_fmac_f32 (VOP2)", "v_lshrrev_b32 (VOP2)", "v_pack_b32_f16 op_sel", "v_cndmask_b32 (VOP2+vcc)"};
     const char* n64[] = {"v_lshl_add_u64", "v_mad_u64_u32", "v_lshrrev_b64", "v_lshlrev_b64", "v_mov_b64"};
     for (int wps = 4; wps <= 8; wps *= 2) {                // waves per SIMD
         const int blocks = 256 * wps;                      // 256 CUs x (wps*4 waves = wps blocks of 256 threads)
@@ -112,7 +144,7 @@ int main() {
 #define RUN32(K) ms = time_ms([&] { hipLaunchKernelGGL(k32<K>, dim3(blocks), dim3(256), 0, 0, (uint32_t*)buf, iters, 7u); }); \
         printf("%-26s %8.3f ms  %8.2f T lane-ops/s  %5.2f cycles/instr/SIMD @2.4GHz\n", n32[K], ms, lane_ops / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)wps * iters * 64));
         RUN32(0) RUN32(1) RUN32(2) RUN32(3) RUN32(4) RUN32(5) RUN32(6) RUN32(7) RUN32(8)
-        RUN32(9) RUN32(10) RUN32(11) RUN32(12) RUN32(13) RUN32(14) RUN32(15) RUN32(16) RUN32(17)
+        RUN32(9) RUN32(10) RUN32(11) RUN32(12) RUN32(13) RUN32(14) RUN32(15) RUN32(16) RUN32(17) RUN32(18) RUN32(19)
 #define RUN64(K) ms = time_ms([&] { hipLaunchKernelGGL(k64<K>, dim3(blocks), dim3(256), 0, 0, (uint64_t*)buf, iters, 7u); }); \
         printf("%-26s %8.3f ms  %8.2f T lane-ops/s  %5.2f cycles/instr/SIMD @2.4GHz\n", n64[K], ms, lane_ops / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)wps * iters * 64));
         RUN64(0) RUN64(1) RUN64(2) RUN64(3) RUN64(4)
