@@ -451,39 +451,85 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
     if (log_N > SH_MAX_LOG_N || ilog2(B) + log_N > 30) return sh_fail(SH_EINVAL, "fri_commit_batch: batch too large (B*N must be <= 2^30)");
     if (!prm) return sh_fail(SH_EINVAL, "fri: null params");
     const uint32_t R = sh_fri_num_rounds(N, prm->expansion, prm->num_colinearity_tests);
+    const size_t L_last = N >> (R ? R - 1 : 0);
     try {
+        // Two lock-step groups on two streams (the context's own and that of an internal second context), each served by its
+        // own host thread, for large batches: the groups drift out of phase, so one group's latency-bound stretches (tree
+        // tops, root hand-off, transcripts) overlap the other's kernels.  Measured: 1024 x 2^14 6.75 -> 6.3 ms; at 128 x 2^14
+        // the two groups stay in phase and the second thread only costs (1.25 -> 1.35 ms), so small batches keep one group.
+        static const bool one_group = getenv("STARK_HIP_BATCH_ONE_GROUP") != nullptr;
+        const size_t G = (!one_group && B >= 32 && R >= 2 && (B << log_N) >= ((size_t)1 << 23)) ? 2 : 1;
+        if (G == 2 && !c->sub) {
+            SHCHK(sh_ctx_create(c->device, nullptr, &c->sub));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
+        }
         unsigned T = std::thread::hardware_concurrency();
         if (T > 8) T = 8;
         if (T > B / 16) T = (unsigned)(B / 16);
-        std::unique_ptr<SpinPool> pool;
-        try { pool.reset(new SpinPool(T > 1 ? T - 1 : 0)); } catch (const std::system_error&) { pool.reset(new SpinPool(0)); }   // no threads to be had: the caller does it all
-        RoundFn fn = [&](uint32_t r, const uint8_t* roots, bool want, fp* alpha_out) -> int32_t {
-            std::atomic<int> failed{0};
-            auto per_codeword = [&](size_t b0, size_t b1) {          // transcripts are independent: one ProofStream per codeword
-                for (size_t b = b0; b < b1; ++b) {
-                    const uint8_t* root = roots + 64 * b;
-                    memcpy(roots_out + 64 * (b * R + r), root, 64);
-                    if (sh_proofstream_push_merkle_root(streams[b], root) != SH_OK) { failed = 1; return; }      // proof_stream.rs:25
-                    if (want) {
-                        uint8_t dig[32];
-                        uint64_t aw[2];
-                        if (sh_proofstream_prover_fiat_shamir(streams[b], dig) != SH_OK) { failed = 1; return; } // proof_stream.rs:51
-                        if (sh_sample_field(dig, aw) != SH_OK) { failed = 1; return; }                           // G3
-                        alpha_out[b] = fp_load_host(aw);
+        const unsigned Tg = G == 2 ? (T / 2 ? T / 2 : 1) : T;
+        auto commit_group = [&](sh_ctx* cx, size_t b_first, size_t Bg, SpinPool* pool) -> int32_t {
+            RoundFn fn = [&, b_first, Bg, pool](uint32_t r, const uint8_t* roots, bool want, fp* alpha_out) -> int32_t {
+                std::atomic<int> failed{0};
+                auto per_codeword = [&](size_t b0, size_t b1) {          // transcripts are independent: one ProofStream per codeword
+                    for (size_t b = b0; b < b1; ++b) {
+                        const uint8_t* root = roots + 64 * b;
+                        sh_proofstream* ps = streams[b_first + b];
+                        memcpy(roots_out + 64 * ((b_first + b) * R + r), root, 64);
+                        if (sh_proofstream_push_merkle_root(ps, root) != SH_OK) { failed = 1; return; }      // proof_stream.rs:25
+                        if (want) {
+                            uint8_t dig[32];
+                            uint64_t aw[2];
+                            if (sh_proofstream_prover_fiat_shamir(ps, dig) != SH_OK) { failed = 1; return; } // proof_stream.rs:51
+                            if (sh_sample_field(dig, aw) != SH_OK) { failed = 1; return; }                   // G3
+                            alpha_out[b] = fp_load_host(aw);
+                        }
                     }
-                }
+                };
+                pool->parallel(Bg, per_codeword);
+                return failed ? sh_fail(SH_ECALLBACK, "fri_commit_batch: transcript update failed") : SH_OK;
             };
-            pool->parallel(B, per_codeword);
-            return failed ? sh_fail(SH_ECALLBACK, "fri_commit_batch: transcript update failed") : SH_OK;
+            size_t ll = 0;
+            SHCHK(fri_commit_core(cx, d_cws + b_first * N, Bg, N, prm, fn, last_out + 2 * b_first * L_last, &ll, nullptr));
+            return SH_OK;
+        };
+        auto make_pool = [](unsigned workers) {
+            std::unique_ptr<SpinPool> p;
+            try { p.reset(new SpinPool(workers)); } catch (const std::system_error&) { p.reset(new SpinPool(0)); }   // no threads to be had: the caller does it all
+            return p;
         };
         const auto t_core0 = std::chrono::steady_clock::now();
-        SHCHK(fri_commit_core(c, d_cws, B, N, prm, fn, last_out, last_len, nullptr));
+        std::unique_ptr<SpinPool> pool0 = make_pool(Tg > 1 ? Tg - 1 : 0);
+        if (G == 1) SHCHK(commit_group(c, 0, B, pool0.get()));
+        else {
+            const size_t B0 = B / 2, B1 = B - B0;
+            HIPCHK(hipEventRecord(c->ev_sync, c->stream));                  // the second stream starts after whatever produced the codewords
+            HIPCHK(hipStreamWaitEvent(c->sub->stream, c->ev_sync, 0));
+            int32_t rc1 = SH_OK;
+            std::string msg1;
+            bool threaded = true;
+            std::thread second;
+            try {
+                second = std::thread([&] {
+                    try {
+                        if (hipSetDevice(c->device) != hipSuccess) { rc1 = SH_EHIP; msg1 = "hipSetDevice failed in the second group's thread"; return; }
+                        std::unique_ptr<SpinPool> pool1 = make_pool(Tg > 1 ? Tg - 1 : 0);
+                        rc1 = commit_group(c->sub, B0, B1, pool1.get());
+                        if (rc1 != SH_OK) msg1 = sh_last_error();
+                    } catch (...) { rc1 = SH_ENOMEM; msg1 = "fri_commit_batch: unexpected exception in the second group's thread"; }
+                });
+            } catch (const std::system_error&) { threaded = false; }
+            const int32_t rc0 = commit_group(c, 0, B0, pool0.get());
+            if (threaded) second.join();
+            else rc1 = commit_group(c->sub, B0, B1, pool0.get());           // no thread to be had: one group after the other
+            if (rc0 != SH_OK) return rc0;
+            if (rc1 != SH_OK) return threaded ? sh_fail(rc1, msg1.c_str()) : rc1;
+        }
+        *last_len = L_last;
         const auto t_tail0 = std::chrono::steady_clock::now();
-        const size_t L = *last_len;
         std::atomic<int> failed{0};
-        pool->parallel(B, [&](size_t b0, size_t b1) { for (size_t b = b0; b < b1; ++b) if (sh_proofstream_push_codeword(streams[b], last_out + 2 * b * L, L) != SH_OK) failed = 1; });
+        pool0->parallel(B, [&](size_t b0, size_t b1) { for (size_t b = b0; b < b1; ++b) if (sh_proofstream_push_codeword(streams[b], last_out + 2 * b * L_last, L_last) != SH_OK) failed = 1; });
         if (failed) return sh_fail(SH_ECALLBACK, "fri_commit_batch: pushing the last codeword failed");
-        if (getenv("STARK_HIP_DEBUG")) fprintf(stderr, "[stark_hip] batch: rounds %.0f us, pushing the last codewords %.0f us\n",
+        if (getenv("STARK_HIP_DEBUG")) fprintf(stderr, "[stark_hip] batch: %zu group(s), rounds %.0f us, pushing the last codewords %.0f us\n", G,
                                                std::chrono::duration<double, std::micro>(t_tail0 - t_core0).count(),
                                                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_tail0).count());
         return SH_OK;

@@ -61,6 +61,8 @@ struct sh_ctx {
     uint8_t* h_chain = nullptr;                  // pinned, device-mapped: root / fold-constant records of a commit's rounds (api_fri.hip)
     uint8_t* d_chain = nullptr;                  // device view of h_chain
     size_t chain_bytes = 0;
+    sh_ctx* sub = nullptr;                       // second stream + buffers for the second lock-step group of a batched commit
+    hipEvent_t ev_sync = nullptr;                // orders the second stream after the first at the start of a batched commit
     uint8_t* h_query = nullptr;                  // pinned staging of the query phase (paths | values | indices | tree table)
     size_t h_query_bytes = 0;
     uint64_t chain_retries = 0;                  // rounds enqueued a second time because a wait kernel ran out of spin

@@ -378,6 +378,29 @@ def test_fri_commit_batch_vs_oracle(ctx, B, log_n):
     co.set_threads(1)
 
 
+def test_large_batch_runs_as_two_groups(ctx):
+    """sh_fri_commit_batch splits a large batch (B·N >= 2^23) into two lock-step groups on two streams served by two host
+    threads; every codeword's roots, last codeword and proof stream must still be its own single commit's — checked
+    against the oracle on both sides of the group boundary and at the ends."""
+    B, log_n = 512, 14
+    N = 1 << log_n
+    d = ctx.alloc(B * N * 16)
+    cws = {}
+    for b in range(B):                                   # seeded per codeword; uploaded slice by slice
+        cw = co.splitmix_elems(7000 + b, N)
+        _lib.check(_lib.lib.sh_dev_upload(ctx.handle, d.ptr + b * N * 16, cw.ctypes.data, N * 16))
+        if b in (0, 1, B // 2 - 1, B // 2, B // 2 + 1, B - 1):
+            cws[b] = cw
+    fri = sa.Fri(G, None, N, 4, 17, ctx=ctx)
+    for _ in range(2):                                   # the second call reuses the second group's context
+        streams = [sa.ProofStream() for _ in range(B)]
+        roots, last = fri.commit_batch(d, streams)
+        for b, cw in cws.items():
+            oroots, _, olast, ops = co.fri_commit(cw, 4, 17, G)
+            assert [r.as_bytes() for r in roots[b]] == oroots and (last[b] == olast).all() and streams[b].serialize() == ops.serialize()
+    d.free()
+
+
 def test_sharded_engine_single_rank(ctx):
     """the product engine behind stark_anatomy_amd.dist (world size 1): same bytes as the oracle per codeword."""
     from stark_anatomy_amd.dist import commit_batch_sharded, gpu_engine
