@@ -120,7 +120,7 @@ struct LevelStore {
 // Without a store the launches ping-pong between `other` and `self` (the buffer `cur` lives in); with one, every launch's
 // output stays: `level0` = log2 of the leaves under one digest of `cur`.
 static int32_t enqueue_forest_reduce(sh_ctx* c, const digest64* cur, digest64* other, digest64* self, uint32_t lg, size_t B, uint8_t* d_rec, uint32_t gen, const uint32_t* d_abort,
-                                     LevelStore* store = nullptr, uint32_t level0 = 0) {
+                                     LevelStore* store = nullptr, uint32_t level0 = 0, digest64* d_roots = nullptr) {
     uint64_t* rec_roots = reinterpret_cast<uint64_t*>(d_rec);
     uint32_t* rec_seq = reinterpret_cast<uint32_t*>(d_rec + B * 64);
     if (lg == 0) { HIPCHK(launch_publish_digests(cur, B, rec_roots, rec_seq, gen, c->stream, d_abort)); return SH_OK; }
@@ -142,7 +142,10 @@ static int32_t enqueue_forest_reduce(sh_ctx* c, const digest64* cur, digest64* o
         }
         if (step == lg) {
             if (B == 1) HIPCHK(launch_quad_reduce(cur, c->d_root, total, step, rec_roots, gen, c->stream, nullptr, 0, d_abort));
-            else {
+            else if (d_roots) {                                    // B roots to device memory, then one small kernel hands them to the host
+                HIPCHK(launch_quad_reduce(cur, d_roots, total, step, nullptr, 0, c->stream, nullptr, 0, d_abort));
+                HIPCHK(launch_publish_digests(d_roots, B, rec_roots, rec_seq, gen, c->stream, d_abort));
+            } else {
                 c->batch_done_total += (uint32_t)B;
                 HIPCHK(launch_quad_reduce(cur, reinterpret_cast<digest64*>(d_rec), total, step, reinterpret_cast<uint64_t*>(d_rec + B * 64 - 64), gen, c->stream,
                                           c->d_flag + 16, c->batch_done_total, d_abort));
@@ -225,6 +228,10 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
         SHCHK(ensure_scratch(c, SCR_DIG_B, (dig0 / 2 ? dig0 / 2 : 1) * sizeof(digest64), &digB));
     }
     SHCHK(ensure_scratch(c, SCR_C0, B * sizeof(fp), &d_c0));
+    void* d_roots_v = nullptr;
+    static const bool publish_kernel = getenv("STARK_HIP_COUNTER_PUBLISH") == nullptr;
+    if (B > 1 && publish_kernel) SHCHK(ensure_scratch(c, SCR_ROOTS, B * sizeof(digest64), &d_roots_v));
+    digest64* d_roots = (digest64*)d_roots_v;
     uint32_t gen = (c->chain_gen + 1) & 0x7fffffffu;
     if (gen == 0) gen = 1;
     c->chain_gen = gen;
@@ -261,16 +268,18 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
         auto small_round = [&](bool fold, const fp* in, fp* out, uint32_t lg_tree) -> int32_t {
             const size_t blocks = ((B << lg_tree) + 127) / 128;
             uint32_t target = 0;
-            if (lg_tree <= 7 && blocks > 1) { c->batch_done_total += (uint32_t)blocks; target = c->batch_done_total; }
+            const bool roots_via_kernel = lg_tree <= 7 && blocks > 1 && d_roots;      // finished roots of several workgroups: to device memory, then k_publish_digests
+            if (lg_tree <= 7 && blocks > 1 && !roots_via_kernel) { c->batch_done_total += (uint32_t)blocks; target = c->batch_done_total; }
             const bool poll_inside = fold && B == 1 && blocks == 1;        // else a wait kernel first: exactly one workgroup ever polls host memory (round_kernels.hip)
             if (fold && !poll_inside)
                 HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)),
                                       (fp*)d_c0, B, d_abort, hd_abort, timeout_ticks, c->stream));
             HIPCHK(launch_round_wg(fold, in, out, lg_tree, B, poll_inside ? reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)) : nullptr, gen,
                                    poll_inside ? reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)) : nullptr, (const fp*)d_c0, d_abort, hd_abort, timeout_ticks, tw_inv, log_N,
-                                   fold ? r - 1 : 0, first, reinterpret_cast<uint64_t*>(rec), reinterpret_cast<uint32_t*>(rec + B * 64), c->d_flag + 16, target,
-                                   c->stream));
-            if (lg_tree > 7) SHCHK(enqueue_forest_reduce(c, first, other, first, lg_tree - 7, B, rec, gen, d_abort, st, 7));
+                                   fold ? r - 1 : 0, roots_via_kernel ? d_roots : first, reinterpret_cast<uint64_t*>(rec), reinterpret_cast<uint32_t*>(rec + B * 64),
+                                   roots_via_kernel ? nullptr : c->d_flag + 16, target, c->stream));
+            if (roots_via_kernel) HIPCHK(launch_publish_digests(d_roots, B, reinterpret_cast<uint64_t*>(rec), reinterpret_cast<uint32_t*>(rec + B * 64), gen, c->stream, d_abort));
+            if (lg_tree > 7) SHCHK(enqueue_forest_reduce(c, first, other, first, lg_tree - 7, B, rec, gen, d_abort, st, 7, d_roots));
             return SH_OK;
         };
         if (r == 0) {
@@ -279,7 +288,7 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
                 const uint32_t K = sh.K;
                 digest64* dst = first ? first : c->d_root;              // a tree that ends in its lanes (N <= 2^K): one digest, the root
                 HIPCHK(launch_leaf_subtree(d_cws, dst, (B * N) >> K, K, c->stream));
-                SHCHK(enqueue_forest_reduce(c, dst, other, dst, log_N - K, B, rec, gen, d_abort, st, K));
+                SHCHK(enqueue_forest_reduce(c, dst, other, dst, log_N - K, B, rec, gen, d_abort, st, K, d_roots));
             }
         } else {
             const size_t L = N >> (r - 1), half = L / 2;
@@ -293,7 +302,7 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
                 const uint32_t K = sh.K;
                 digest64* dst = first ? first : c->d_root;
                 HIPCHK(launch_fold_leaf_subtree(in, L, B, (const fp*)d_c0, fp_zero(), tw_inv, log_N, r - 1, next, dst, K, c->stream, d_abort));
-                SHCHK(enqueue_forest_reduce(c, dst, other, dst, ilog2(half) - K, B, rec, gen, d_abort, st, K));
+                SHCHK(enqueue_forest_reduce(c, dst, other, dst, ilog2(half) - K, B, rec, gen, d_abort, st, K, d_roots));
             }
         }
         ++enq;

@@ -169,8 +169,9 @@ __global__ __launch_bounds__(RW_THREADS) void k_round_wg(const RoundArgs a) {
     const uint32_t levels = a.log_half < RW_CHUNK_LOG ? a.log_half : RW_CHUNK_LOG;  // active is a multiple of 2^levels (launcher)
     const uint32_t s_off = quad_tree_levels(sm, D, 0, active, levels, tid, RW_THREADS, L);
     const uint32_t nout = active >> levels;
-    if (levels == a.log_half) quad_publish_roots(sm, s_off, nout, j0 >> a.log_half, a.rec_roots, a.rec_seq, a.gen, gridDim.x > 1 ? a.counter : nullptr, a.target, tid, RW_THREADS);
-    else
+    if (levels == a.log_half && (gridDim.x == 1 || a.counter))
+        quad_publish_roots(sm, s_off, nout, j0 >> a.log_half, a.rec_roots, a.rec_seq, a.gen, gridDim.x > 1 ? a.counter : nullptr, a.target, tid, RW_THREADS);
+    else                                           // sub-roots for the reduction above — or finished roots (several workgroups, no counter) for k_publish_digests
         for (uint32_t i = tid; i < nout * 8; i += RW_THREADS) a.sub_out[(size_t)blockIdx.x * nout + (i >> 3)].h[i & 7] = sm[s_off + QR_DIGEST_OFF(i >> 3) + (i & 7)];
 }
 
@@ -181,6 +182,7 @@ hipError_t launch_round_wg(bool fold, const fp* cw, fp* out, uint32_t log_half, 
     const size_t total = B << log_half;
     if (!B || total > ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL) || log_half == 0 || log_half > ROUND_WG_MAX_LOG_TOTAL) return hipErrorInvalidValue;
     if (log_half > RW_CHUNK_LOG && !sub_out) return hipErrorInvalidValue;
+    if (log_half <= RW_CHUNK_LOG && total > RW_CHUNK && !counter && !sub_out) return hipErrorInvalidValue;    // roots of several workgroups need one of the two ways out
     const unsigned blocks = (unsigned)((total + RW_CHUNK - 1) / RW_CHUNK);
     // ONE poller only.  With lane 0 of 2-32 workgroups polling the same host line, one of them now and then kept reading the
     // previous commit's value for the whole timeout (700k polls in a second, host memory already updated): measured, two contexts
