@@ -101,6 +101,7 @@ int32_t sh_ctx_destroy(sh_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->sub) { (void)sh_ctx_destroy(c->sub); c->sub = nullptr; (void)hipSetDevice(c->device); }
     if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
+    delete c->pool;
     if (getenv("STARK_HIP_DEBUG")) fprintf(stderr, "[stark_hip] ctx %p: mailbox roots %u, fallbacks %llu\n", (void*)c, c->mail_seq, (unsigned long long)c->mail_fallbacks);
     for (auto& kv : c->tw_cache) (void)hipFree(kv.second);
     for (int i = 0; i < NUM_SCRATCH; ++i) if (c->scratch[i]) (void)hipFree(c->scratch[i]);

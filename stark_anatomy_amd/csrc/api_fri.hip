@@ -352,9 +352,10 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
         SHCHK(fn(r, c->h_chain + lay.roots(r), want, alpha.data()));
         if (want) {
             fp* h_c0 = reinterpret_cast<fp*>(c->h_chain + lay.c0(r));
+            const fp k_rr = fp_to_mont(fp_to_mont(fp_mul(inv2, off_inv)));            // 2^-1 · offset_r^-1 · R^2: one multiply per codeword below
             for (size_t b = 0; b < B; ++b) {
                 if (!fp_is_canonical(alpha[b])) return sh_fail(SH_EINVAL, "fri_commit: callback returned a non-canonical alpha");
-                h_c0[b] = fp_to_mont(fp_mul(fp_mul(alpha[b], inv2), off_inv));        // c0 = alpha · 2^-1 · offset_r^-1
+                h_c0[b] = mont_mul(alpha[b], k_rr);                                   // c0 = alpha · 2^-1 · offset_r^-1, in Montgomery form
             }
             __atomic_store_n(reinterpret_cast<uint32_t*>(c->h_chain + lay.c0_seq(r)), gen, __ATOMIC_RELEASE);
             guard.next_c0 = r + 1;
@@ -399,50 +400,6 @@ int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_params*
     } catch (const std::bad_alloc&) { return sh_fail(SH_ENOMEM, "fri_commit: out of host memory");
     } catch (...) { return sh_fail(SH_ENOMEM, "fri_commit: unexpected exception on the host side"); }
 }
-
-// Worker threads that live for one batched commit and are handed one slice of the B transcripts per round.  They spin
-// (then yield) between rounds: a round's hand-off must cost well under the ~10 us a thread spawn does.
-class SpinPool {
-  public:
-    explicit SpinPool(unsigned workers) {
-        for (unsigned w = 0; w < workers; ++w) th_.emplace_back([this, w] { run(w); });
-    }
-    ~SpinPool() {
-        stop_.store(true, std::memory_order_relaxed);
-        gen_.fetch_add(1, std::memory_order_release);
-        for (auto& t : th_) t.join();
-    }
-    // f(b0, b1) over [0, n) split into workers + 1 contiguous slices; the caller takes the first
-    template <class F>
-    void parallel(size_t n, F&& f) {
-        const size_t T = th_.size() + 1, chunk = (n + T - 1) / T;
-        std::function<void(size_t, size_t)> fn = f;
-        fn_ = &fn; n_ = n; chunk_ = chunk;
-        pending_.store((int)th_.size(), std::memory_order_relaxed);
-        gen_.fetch_add(1, std::memory_order_release);
-        fn(0, chunk < n ? chunk : n);
-        while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
-    }
-  private:
-    void run(unsigned w) {
-        uint64_t seen = 0;
-        for (;;) {
-            uint32_t spins = 0;
-            while (gen_.load(std::memory_order_acquire) == seen) { if (++spins > 4000) std::this_thread::yield(); else __builtin_ia32_pause(); }
-            ++seen;
-            if (stop_.load(std::memory_order_relaxed)) return;
-            const size_t b0 = (size_t)(w + 1) * chunk_, b1 = b0 + chunk_;
-            (*fn_)(b0 < n_ ? b0 : n_, b1 < n_ ? b1 : n_);
-            pending_.fetch_sub(1, std::memory_order_release);
-        }
-    }
-    std::vector<std::thread> th_;
-    std::atomic<uint64_t> gen_{0};
-    std::atomic<int> pending_{0};
-    std::atomic<bool> stop_{false};
-    const std::function<void(size_t, size_t)>* fn_ = nullptr;
-    size_t n_ = 0, chunk_ = 0;
-};
 
 // ------------------------------------------------------------------ batched FRI commit (lock-step rounds)
 // B independent codewords of equal length, back to back.  Every kernel of a round covers all B codewords, so the
@@ -501,18 +458,27 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
             SHCHK(fri_commit_core(cx, d_cws + b_first * N, Bg, N, prm, fn, last_out + 2 * b_first * L_last, &ll, nullptr));
             return SH_OK;
         };
-        auto make_pool = [](unsigned workers) {
-            std::unique_ptr<SpinPool> p;
-            try { p.reset(new SpinPool(workers)); } catch (const std::system_error&) { p.reset(new SpinPool(0)); }   // no threads to be had: the caller does it all
-            return p;
+        // the context's transcript workers (created once, asleep between calls: creating seven threads costs ~120 us per call)
+        auto pool_of = [&](sh_ctx* cx) -> SpinPool* {
+            if (!cx->pool) {
+                unsigned hw = std::thread::hardware_concurrency();
+                if (hw > 8) hw = 8;
+                try { cx->pool = new SpinPool(hw > 1 ? hw - 1 : 0); } catch (const std::system_error&) { cx->pool = new SpinPool(0); }   // no threads to be had: the caller does it all
+            }
+            cx->pool->wake(Tg);
+            return cx->pool;
         };
+        struct Parker { SpinPool* p = nullptr; ~Parker() { if (p) p->park(); } } park0, park1;
         const auto t_core0 = std::chrono::steady_clock::now();
-        std::unique_ptr<SpinPool> pool0 = make_pool(Tg > 1 ? Tg - 1 : 0);
-        if (G == 1) SHCHK(commit_group(c, 0, B, pool0.get()));
+        SpinPool* pool0 = pool_of(c);
+        park0.p = pool0;
+        if (G == 1) SHCHK(commit_group(c, 0, B, pool0));
         else {
             const size_t B0 = B / 2, B1 = B - B0;
             HIPCHK(hipEventRecord(c->ev_sync, c->stream));                  // the second stream starts after whatever produced the codewords
             HIPCHK(hipStreamWaitEvent(c->sub->stream, c->ev_sync, 0));
+            SpinPool* pool1 = pool_of(c->sub);
+            park1.p = pool1;
             int32_t rc1 = SH_OK;
             std::string msg1;
             bool threaded = true;
@@ -521,15 +487,14 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
                 second = std::thread([&] {
                     try {
                         if (hipSetDevice(c->device) != hipSuccess) { rc1 = SH_EHIP; msg1 = "hipSetDevice failed in the second group's thread"; return; }
-                        std::unique_ptr<SpinPool> pool1 = make_pool(Tg > 1 ? Tg - 1 : 0);
-                        rc1 = commit_group(c->sub, B0, B1, pool1.get());
+                        rc1 = commit_group(c->sub, B0, B1, pool1);
                         if (rc1 != SH_OK) msg1 = sh_last_error();
                     } catch (...) { rc1 = SH_ENOMEM; msg1 = "fri_commit_batch: unexpected exception in the second group's thread"; }
                 });
             } catch (const std::system_error&) { threaded = false; }
-            const int32_t rc0 = commit_group(c, 0, B0, pool0.get());
+            const int32_t rc0 = commit_group(c, 0, B0, pool0);
             if (threaded) second.join();
-            else rc1 = commit_group(c->sub, B0, B1, pool0.get());           // no thread to be had: one group after the other
+            else rc1 = commit_group(c->sub, B0, B1, pool0);           // no thread to be had: one group after the other
             if (rc0 != SH_OK) return rc0;
             if (rc1 != SH_OK) return threaded ? sh_fail(rc1, msg1.c_str()) : rc1;
         }

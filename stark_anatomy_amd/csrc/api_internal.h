@@ -8,6 +8,8 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <functional>
 #include <map>
 #include <memory>
@@ -35,6 +37,69 @@
         HIPCHK(hipSetDevice((c)->device));                                 \
     } while (0)
 
+// Worker threads of a context that are handed one slice of the B transcripts of a batched commit per round.  Awake, they
+// spin (then yield) between rounds: a round's hand-off must cost well under the ~10 us a wake-up does.  Between calls
+// they sleep on a condition variable.
+class SpinPool {
+  public:
+    explicit SpinPool(unsigned workers) {
+        for (unsigned w = 0; w < workers; ++w) th_.emplace_back([this, w] { run(w); });
+    }
+    ~SpinPool() {
+        { std::lock_guard<std::mutex> g(m_); stop_.store(true, std::memory_order_relaxed); awake_.store(true, std::memory_order_release); }
+        cv_.notify_all();
+        gen_.fetch_add(1, std::memory_order_release);
+        for (auto& t : th_) t.join();
+    }
+    // `use` threads (the caller included) share the work until park()
+    void wake(unsigned use) {
+        use_ = use < 1 ? 1 : (use > th_.size() + 1 ? (unsigned)th_.size() + 1 : use);
+        { std::lock_guard<std::mutex> g(m_); awake_.store(true, std::memory_order_release); }
+        cv_.notify_all();
+    }
+    void park() { awake_.store(false, std::memory_order_release); }
+    // f(b0, b1) over [0, n) split into `use` contiguous slices; the caller takes the first
+    template <class F>
+    void parallel(size_t n, F&& f) {
+        const size_t T = use_, chunk = (n + T - 1) / T;
+        std::function<void(size_t, size_t)> fn = f;
+        fn_ = &fn; n_ = n; chunk_ = chunk;
+        pending_.store((int)th_.size(), std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        fn(0, chunk < n ? chunk : n);
+        while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    }
+  private:
+    void run(unsigned w) {
+        uint64_t seen = 0;
+        for (;;) {
+            uint32_t spins = 0;
+            while (gen_.load(std::memory_order_acquire) == seen) {
+                if (!awake_.load(std::memory_order_acquire)) {
+                    std::unique_lock<std::mutex> g(m_);
+                    cv_.wait(g, [this, seen] { return awake_.load(std::memory_order_acquire) || gen_.load(std::memory_order_acquire) != seen; });
+                    spins = 0;
+                } else if (++spins > 4000) std::this_thread::yield();
+                else __builtin_ia32_pause();
+            }
+            ++seen;
+            if (stop_.load(std::memory_order_relaxed)) return;
+            const size_t b0 = (size_t)(w + 1) * chunk_, b1 = b0 + chunk_;
+            if (w + 1 < use_) (*fn_)(b0 < n_ ? b0 : n_, b1 < n_ ? b1 : n_);
+            pending_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> pending_{0};
+    std::atomic<bool> stop_{false}, awake_{false};
+    const std::function<void(size_t, size_t)>* fn_ = nullptr;
+    size_t n_ = 0, chunk_ = 0;
+    unsigned use_ = 1;
+};
+
 // ------------------------------------------------------------------ context
 #define NUM_SCRATCH 14
 enum { SCR_IO_A = 0, SCR_IO_B = 1, SCR_IO_C = 2, SCR_WORK = 3, SCR_DIG_A = 4, SCR_DIG_B = 5, SCR_ROOTS = 6, SCR_C0 = 7,
@@ -61,6 +126,7 @@ struct sh_ctx {
     uint8_t* h_chain = nullptr;                  // pinned, device-mapped: root / fold-constant records of a commit's rounds (api_fri.hip)
     uint8_t* d_chain = nullptr;                  // device view of h_chain
     size_t chain_bytes = 0;
+    SpinPool* pool = nullptr;                    // transcript workers of batched commits (asleep between calls)
     sh_ctx* sub = nullptr;                       // second stream + buffers for the second lock-step group of a batched commit
     hipEvent_t ev_sync = nullptr;                // orders the second stream after the first at the start of a batched commit
     uint8_t* h_query = nullptr;                  // pinned staging of the query phase (paths | values | indices | tree table)
