@@ -5,6 +5,7 @@
 # Everything lands in gpurun_out/evidence/; tools/evidence_table.py turns it into the tables under profiles/.
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
+export STARK_HIP_CHAIN_SPIN_US=200000   # the profiler slows the host side: do not let wait kernels give up and re-launch rounds while it watches
 OUT=gpurun_out/evidence
 rm -rf $OUT && mkdir -p $OUT
 run() { echo "== $*" >> $OUT/log.txt; "$@" >> $OUT/log.txt 2>&1; }
