@@ -106,13 +106,17 @@ def main():
 
     import ctypes as C
 
+    out_bufs = {}
+
     def commit(dbuf, n):
-        R = int(_lib.lib.sh_fri_num_rounds(n, 4, 17))
-        roots = np.zeros((max(R, 1), 64), dtype=np.uint8)
-        last = np.empty((n >> max(R - 1, 0), 2), dtype=np.uint64)
-        last_len = C.c_size_t(0)
+        if n not in out_bufs:                                  # output buffers once per size; a fresh (empty) transcript per commit
+            R = int(_lib.lib.sh_fri_num_rounds(n, 4, 17))
+            roots = np.zeros((max(R, 1), 64), dtype=np.uint8)
+            last = np.empty((n >> max(R - 1, 0), 2), dtype=np.uint64)
+            out_bufs[n] = (roots, last, _u8p(roots), _u64p(last), C.c_size_t(0))
+        roots, last, p_roots, p_last, last_len = out_bufs[n]
         ps = sa.ProofStream()
-        _lib.check(_lib.lib.sh_dev_fri_commit_proofstream(H, dbuf.ptr, n, C.byref(params), ps.handle, _u8p(roots), _u64p(last), C.byref(last_len)))
+        _lib.check(_lib.lib.sh_dev_fri_commit_proofstream(H, dbuf.ptr, n, C.byref(params), ps.handle, p_roots, p_last, C.byref(last_len)))
         return roots, ps
 
     def timed(fn, steps, warmup):
