@@ -483,6 +483,7 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
             std::string msg1;
             bool threaded = true;
             std::thread second;
+            struct JoinOnExit { std::thread& t; ~JoinOnExit() { if (t.joinable()) t.join(); } } join_on_exit{second};   // also when this thread unwinds
             try {
                 second = std::thread([&] {
                     try {
