@@ -282,8 +282,30 @@ int32_t sh_dev_coset_lde(sh_ctx* c, const uint64_t* d_coeffs, uint32_t log_n, ui
     const fp off = fp_load_host(offset);
     if (!fp_is_canonical(off)) return sh_fail(SH_EINVAL, "sh_dev_coset_lde: non-canonical offset");
     const size_t n = (size_t)1 << log_n, N = n << log_expansion;
-    HIPCHK(launch_coset_scale_pad((const fp*)d_coeffs, n, off, (fp*)d_out, N, c->stream));
-    return dev_ntt(c, (fp*)d_out, log_n + log_expansion, false);
+    const uint32_t log_N = log_n + log_expansion;
+    NttPlan plan;
+    ntt_make_plan(log_N, &plan);
+    NttLdeShape sh;
+    static const bool no_fuse = getenv("STARK_NO_LDE_FUSE") != nullptr;
+    if (no_fuse || d_coeffs == d_out || !ntt_lde_fusable(plan, log_expansion, &sh)) {
+        HIPCHK(launch_coset_scale_pad((const fp*)d_coeffs, n, off, (fp*)d_out, N, c->stream));
+        return dev_ntt(c, (fp*)d_out, log_N, false);
+    }
+    // Fused form: no zero-padded, pre-scaled copy of the coefficients is ever written — the first NTT pass reads the n
+    // coefficients, scales them by offset^j on the way into LDS and never touches the padding (one HBM pass less).
+    const fp* tw;
+    SHCHK(get_twiddles(c, log_N, false, &tw));
+    void *scratch, *tab;
+    SHCHK(ensure_scratch(c, SCR_WORK, N * sizeof(fp), &scratch));
+    SHCHK(ensure_scratch(c, SCR_LDE_TAB, (sh.rows + sh.chunks + sh.cols) * sizeof(fp), &tab));
+    fp* pow_row = (fp*)tab, *pow_chunk = pow_row + sh.rows, *pow_col = pow_chunk + sh.chunks;
+    auto pow2k = [&](uint32_t k) { fp b = fp_to_mont(off); for (uint32_t i = 0; i < k; ++i) b = mont_mul(b, b); return b; };   // offset^(2^k), Montgomery form
+    HIPCHK(launch_pow_table(pow_row, sh.rows, pow2k(sh.log_row_stride), c->stream));
+    HIPCHK(launch_pow_table(pow_chunk, sh.chunks, pow2k(sh.log_cols), c->stream));
+    HIPCHK(launch_pow_table(pow_col, sh.cols, pow2k(0), c->stream));
+    const NttLdeFuse fuse{(const fp*)d_coeffs, log_expansion, pow_row, pow_chunk, pow_col};
+    HIPCHK(launch_ntt(plan, (fp*)d_out, (fp*)scratch, tw, fp_mont_one(), false, 1, c->stream, &fuse));
+    return SH_OK;
 }
 int32_t sh_coset_lde(sh_ctx* c, const uint64_t* coeffs, uint32_t log_n, uint32_t log_expansion, const uint64_t offset[2], uint64_t* out) {
     CTXCHK(c);

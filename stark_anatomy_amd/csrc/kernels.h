@@ -55,7 +55,15 @@ void ntt_make_plan(uint32_t log_n, NttPlan* plan);
 // scale_mont: Montgomery-form factor applied at the final store (R mod p == 1, or n^-1·R for the inverse).
 // `data` is transformed in place; `scratch` holds n elements.
 // `batch` contiguous transforms of 2^plan.log_n elements each; `scratch` holds as many elements as `data`.
-hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s);
+// Coset LDE fused into the first pass (plans of >= 2 passes, batch 1): that pass reads the n = N >> log_expansion coefficients
+// from `coeffs` instead of a zero-padded, pre-scaled copy in `data`, and multiplies each by offset^j from three small tables of
+// Montgomery-form powers (launch_pow_table): pow_row[r] = offset^(r << log_row_stride), r < rows; pow_chunk[k] = offset^(k << log_cols),
+// k < chunks; pow_col[c] = offset^c, c < cols — shapes from ntt_lde_fusable.
+struct NttLdeShape { size_t rows, chunks, cols; uint32_t log_row_stride, log_cols; };
+struct NttLdeFuse { const fp* coeffs; uint32_t log_expansion; const fp *pow_row, *pow_chunk, *pow_col; };
+bool ntt_lde_fusable(const NttPlan& plan, uint32_t log_expansion, NttLdeShape* shape);
+hipError_t launch_pow_table(fp* out, size_t count, fp base_mont, hipStream_t s);
+hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s, const NttLdeFuse* fuse = nullptr);
 hipError_t launch_scale_powers(fp* data, size_t count, fp start_mont, fp base, hipStream_t s);
 hipError_t launch_twiddle_scale(fp* data, size_t rows, uint32_t log_cols, uint64_t row0, uint64_t col0, const fp* tw, uint32_t log_n, hipStream_t s);
 // out[j] = j < n ? coeffs[j]·offset^j : 0   for j < N  (coset pre-scale + zero pad, G7)

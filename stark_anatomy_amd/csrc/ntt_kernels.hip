@@ -32,6 +32,11 @@ struct NttPassParams {
     uint32_t apply_scale;
     uint32_t log_tiles;           // tiles per transform (log2); blockIdx.x >> log_tiles = index in the batch
     fp scale;                     // Montgomery form
+    // first pass of a coset LDE (fuse_log_e > 0): `in` holds only the n = 2^(log_n - fuse_log_e) coefficients; the rows of a
+    // tile that fall into the zero padding are not read, and a coefficient is scaled by offset^j on its way into LDS.
+    // Montgomery-form power tables: pow_row[r] = offset^(r·n/R... the row stride), pow_chunk[k] = offset^(k·C), pow_col[c] = offset^c.
+    uint32_t fuse_log_e;
+    const fp *pow_row, *pow_chunk, *pow_col;
 };
 
 __device__ __forceinline__ fp ntt_load_tw(const fp* __restrict__ tw, uint32_t log_n, size_t e) {
@@ -102,6 +107,18 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams p) {
         colbase = (uint32_t)(chunk << p.log_c);
         base = (block << p.log_m) + colbase;
         row_stride_in = (size_t)1 << log_mp;
+        if (p.fuse_log_e) {                                       // j = r·row_stride + colbase + c;  x = j < n ? coeff[j]·offset^j : 0
+            fp* pc = twr + (R >> 1);                              // offset^(colbase + c), c < C
+            if (tid < C) pc[tid] = mont_mul(p.pow_chunk[chunk], p.pow_col[tid]);
+            __syncthreads();
+            const uint32_t r_n = R >> p.fuse_log_e;               // rows below it hold coefficients
+            for (uint32_t idx = tid; idx < T; idx += blockDim.x) {
+                const uint32_t r = idx >> p.log_c, c = idx & (C - 1);
+                fp v = fp_zero();
+                if (r < r_n) v = mont_mul(in[base + (size_t)r * row_stride_in + c], mont_mul(p.pow_row[r], pc[c]));
+                x[r * rs + c] = v;
+            }
+        } else
         for (uint32_t idx = tid; idx < T; idx += blockDim.x) {
             const uint32_t r = idx >> p.log_c, c = idx & (C - 1);
             x[r * rs + c] = in[base + (size_t)r * row_stride_in + c];
@@ -189,10 +206,39 @@ void ntt_make_plan(uint32_t log_n, NttPlan* plan) {
 static size_t pass_lds_bytes(uint32_t log_r, uint32_t log_c, bool is_final) {
     const size_t R = (size_t)1 << log_r, C = (size_t)1 << log_c;
     const size_t rs = (is_final && log_c) ? C + 1 : C;
-    return (R * rs + (R >> 1) + 1) * sizeof(fp);
+    return (R * rs + (R >> 1) + 1 + C) * sizeof(fp);           // tile | w_R powers | C column powers of a fused LDE load
 }
 
-hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s) {
+// out[k] = base^k in Montgomery form, k < count (base_mont = base·2^128)
+__global__ __launch_bounds__(256) void k_pow_table(fp* __restrict__ out, uint32_t count, fp base_mont) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    fp acc = fp_mont_one(), b = base_mont;
+    for (uint32_t e = k; e; e >>= 1) {
+        if (e & 1) acc = mont_mul(acc, b);
+        b = mont_mul(b, b);
+    }
+    out[k] = acc;
+}
+hipError_t launch_pow_table(fp* out, size_t count, fp base_mont, hipStream_t s) {
+    if (!count) return hipSuccess;
+    if (count > 0xffffffffu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pow_table, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, out, (uint32_t)count, base_mont);
+    return hipGetLastError();
+}
+bool ntt_lde_fusable(const NttPlan& plan, uint32_t log_expansion, NttLdeShape* shape) {
+    if (plan.num_passes < 2 || log_expansion == 0 || log_expansion > plan.bits[0]) return false;
+    const uint32_t log_r = plan.bits[0], log_mp = plan.log_n - log_r;
+    const uint32_t log_c = (12 - log_r) < log_mp ? (12 - log_r) : log_mp;
+    shape->rows = (size_t)1 << (log_r - log_expansion);
+    shape->chunks = (size_t)1 << (log_mp - log_c);
+    shape->cols = (size_t)1 << log_c;
+    shape->log_row_stride = log_mp;
+    shape->log_cols = log_c;
+    return true;
+}
+
+hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s, const NttLdeFuse* fuse) {
     static bool attr_set[64] = {};             // per device: the attribute belongs to the function on the current device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -218,6 +264,11 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
             p.log_c = (12 - p.log_r) < log_mp ? (12 - p.log_r) : log_mp;
             p.in = data;                                               // non-final passes work in place on `data` ...
             p.out = (pi + 2 == P) ? scratch : data;                    // ... except the last one, which lands in scratch
+            if (pi == 0 && fuse) {                                     // coset LDE: the first pass reads the coefficients themselves
+                if (batch != 1) return hipErrorInvalidValue;
+                p.in = fuse->coeffs; p.fuse_log_e = fuse->log_expansion;
+                p.pow_row = fuse->pow_row; p.pow_chunk = fuse->pow_chunk; p.pow_col = fuse->pow_col;
+            }
         } else {
             p.log_r0 = (P >= 2) ? plan.bits[0] : 0;
             p.log_c = (12 - p.log_r) < p.log_r0 ? (12 - p.log_r) : p.log_r0;
