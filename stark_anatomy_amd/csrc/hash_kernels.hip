@@ -181,16 +181,19 @@ __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const 
 // K = 3 form of the same kernel with HBM access staged through LDS.  In the plain form lane i reads lo[8i+q], hi[8i+q] and
 // writes out[8i+q] one q at a time, 128 bytes apart from its neighbours: every 128-byte line is touched 8 times over the
 // ~100 us a subtree takes, the lines in flight per XCD (~6 MB) overflow its 4 MB L2, and rocprof shows 4x the algorithmic
-// read traffic (2x for writes).  Here each wave first copies its 512 lo and 512 hi elements with fully coalesced loads
-// into LDS (rows of 8 elements padded to 9 so the later per-lane reads spread over the banks), folds out of LDS, parks
-// the results in the lo slots and writes them back coalesced at the end.  18.4 KB of LDS per wave: 8 waves per CU.
+// read traffic (2x for writes).  Here a wave first FOLDS its 512 outputs in coalesced order — lane l takes outputs
+// l, 64+l, ...: one coalesced 1 KB read of each half, the fold, one coalesced 1 KB write of the result per step — and parks
+// the results in LDS (rows of 8 padded to 9 so the later per-lane reads spread over the banks); then every lane hashes its
+// own 8 consecutive results out of LDS.  9.2 KB of LDS per wave, so the kernel runs as many waves as its registers allow
+// (3 per SIMD); the first staged form kept both input halves in LDS (18.4 KB per wave), ran 2 waves per SIMD and was ~10 %
+// slower for it.
 #define STAGE_ROW 9
 #define STAGE_WAVE_ELEMS (64 * STAGE_ROW)
 __global__ __launch_bounds__(256, 2) void k_fold_leaf_subtree_staged(const fp* __restrict__ cw, uint32_t log_half, const fp* __restrict__ c0_arr, fp c0_single,
                                                                      const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
                                                                      fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out,
                                                                      const uint32_t* __restrict__ d_abort) {
-    __shared__ fp s_lo[4 * STAGE_WAVE_ELEMS], s_hi[4 * STAGE_WAVE_ELEMS];
+    __shared__ fp s_v[4 * STAGE_WAVE_ELEMS];
     if (d_abort && __hip_atomic_load(d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // n_out is a multiple of 64: whole waves are in or out
@@ -201,29 +204,21 @@ __global__ __launch_bounds__(256, 2) void k_fold_leaf_subtree_staged(const fp* _
     const fp c0_mont = c0_arr ? c0_arr[b] : c0_single;
     const fp* lo = cw + (b << (log_half + 1)) + ww0;
     const fp* hi = lo + half;
-    fp* my_lo = s_lo + wave * STAGE_WAVE_ELEMS;
-    fp* my_hi = s_hi + wave * STAGE_WAVE_ELEMS;
-#pragma unroll
+    fp* mine = s_v + wave * STAGE_WAVE_ELEMS;
+#pragma unroll 2
     for (uint32_t t = 0; t < 8; ++t) {
         const uint32_t e = t * 64 + lane;
-        my_lo[e + (e >> 3)] = lo[e];
-        my_hi[e + (e >> 3)] = hi[e];
+        const fp tw = mont_mul(load_tw(tw_inv, log_n_table, (ww0 + e) << tw_shift), c0_mont);
+        const fp v = fold_one(lo[e], hi[e], tw);
+        out[wj0 + e] = v;
+        mine[e + (e >> 3)] = v;
     }
     __syncthreads();
-    const size_t w0 = ww0 + ((size_t)lane << 3);
     digest64 d = subtree_reduce(3, [&](uint32_t q) {
-        fp t = mont_mul(load_tw(tw_inv, log_n_table, (w0 + q) << tw_shift), c0_mont);
-        fp v = fold_one(my_lo[lane * STAGE_ROW + q], my_hi[lane * STAGE_ROW + q], t);
-        my_lo[lane * STAGE_ROW + q] = v;
+        const fp v = mine[lane * STAGE_ROW + q];
         return b2b_leaf(fp_lo64(v), fp_hi64(v));
     });
     store_digest(digests + i, d);
-    __syncthreads();
-#pragma unroll
-    for (uint32_t t = 0; t < 8; ++t) {
-        const uint32_t e = t * 64 + lane;
-        out[wj0 + e] = my_lo[e + (e >> 3)];
-    }
 }
 
 // The same staging for the first round's leaf-only kernel (K = 3): one coalesced 8 KB read per wave instead of 8 strided
