@@ -212,17 +212,24 @@ def main():
         roots_b = np.zeros((Bb, Rb, 64), dtype=np.uint8)
         last_b = np.empty((Bb, nb >> (Rb - 1), 2), dtype=np.uint64)
 
-        # fresh (empty) transcripts for every call, made before the clock starts: creating 128 Python objects is not the library's time
-        fresh = [[sa.ProofStream() for _ in range(Bb)] for _ in range(max(5, args.steps) + 2)]
-        fresh_handles = [(_lib.ps_t * Bb)(*[p.handle for p in pss]) for pss in fresh]
+        # fresh (empty) transcripts for every call, made before the clock starts: creating 128 Python objects is not the library's time.
+        # The whole leg runs twice and the second pass is the one timed: the first pass's transcripts are freed before the second's
+        # are made, so their items grow into heap memory that has been touched before, as in a process that commits batch after
+        # batch (on never-touched heap the page faults of ~0.6 MB of transcript items add ~0.2 ms per call).
+        n_calls = max(5, args.steps) + 2
         calls = [0]
+        fresh_handles = []
 
         def batch_commit():
             ll = C.c_size_t(0)
             handles = fresh_handles[calls[0]]; calls[0] += 1
             _lib.check(_lib.lib.sh_dev_fri_commit_batch(H, d_b.ptr, Bb, nb, C.byref(params), handles, _u8p(roots_b), _u64p(last_b), C.byref(ll)))
-        dt_b = timed(batch_commit, max(5, args.steps), 2)
-        del fresh, fresh_handles
+        for timed_pass in (False, True):
+            fresh = [[sa.ProofStream() for _ in range(Bb)] for _ in range(n_calls)]
+            fresh_handles = [(_lib.ps_t * Bb)(*[p.handle for p in pss]) for pss in fresh]
+            calls[0] = 0
+            dt_b = timed(batch_commit, max(5, args.steps), 2)
+            del fresh, fresh_handles
         extra["batch_128x2^14_elems_per_s"] = world * Bb * nb * max(5, args.steps) / dt_b
         extra["batch_128x2^14_ms"] = 1e3 * dt_b / max(5, args.steps)
         d_b.free()

@@ -17,9 +17,15 @@ p = _lib.FriParams(); p.expansion, p.num_colinearity_tests = 4, 17
 p.offset[0], p.offset[1] = sa.GENERATOR & 0xFFFFFFFFFFFFFFFF, sa.GENERATOR >> 64
 R = int(_lib.lib.sh_fri_num_rounds(n, 4, 17))
 roots = np.zeros((B, R, 64), dtype=np.uint8); last = np.empty((B, n >> (R - 1), 2), dtype=np.uint64); ll = C.c_size_t(0)
+pre = os.environ.get("PRE") == "1"              # PRE=1: all transcripts made up front, calls back to back (as bench.py does)
+if pre:
+    all_pss = [[sa.ProofStream() for _ in range(B)] for _ in range(6)]
+    all_handles = [(_lib.ps_t * B)(*[q.handle for q in pss]) for pss in all_pss]
 for it in range(6):
-    pss = [sa.ProofStream() for _ in range(B)]
-    handles = (_lib.ps_t * B)(*[q.handle for q in pss])
+    if pre: handles = all_handles[it]
+    else:
+        pss = [sa.ProofStream() for _ in range(B)]
+        handles = (_lib.ps_t * B)(*[q.handle for q in pss])
     t0 = time.perf_counter()
     _lib.check(_lib.lib.sh_dev_fri_commit_batch(H, d.ptr, B, n, C.byref(p), handles, _u8p(roots), _u64p(last), C.byref(ll)))
     dt = time.perf_counter() - t0
