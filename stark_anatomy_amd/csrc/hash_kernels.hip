@@ -20,10 +20,12 @@
 #define SUBTREE_WAVES 1
 #endif
 
-// Depth-first reduction of 2^K items produced by `leaf(i)` (i ascending) to one digest.
-// Every loop bound and stack index is wave-uniform.
-template <class LeafFn>
+// Depth-first reduction of 2^K items produced by `leaf(i)` (i ascending) to one digest, K <= KMAX <= 4.
+// Every loop bound and stack index is wave-uniform.  The stack of pending left siblings is KMAX digests of 16 VGPRs each: a
+// kernel whose K is fixed says so (KMAX = K) and does not carry the registers of levels it never reaches.
+template <int KMAX = SUBTREE_KMAX, class LeafFn>
 __device__ __forceinline__ digest64 subtree_reduce(uint32_t K, LeafFn leaf) {
+    static_assert(KMAX >= 1 && KMAX <= 4, "subtree stack depth");
     digest64 lv0, lv1, lv2, lv3, cur;
     const uint32_t count = 1u << K;
 #pragma unroll 1
@@ -33,19 +35,17 @@ __device__ __forceinline__ digest64 subtree_reduce(uint32_t K, LeafFn leaf) {
 #pragma unroll 1
         for (; (i >> j) & 1u; ++j) {
             digest64 left;
-            switch (j) {
-            case 0: left = lv0; break;
-            case 1: left = lv1; break;
-            case 2: left = lv2; break;
-            default: left = lv3; break;
-            }
+            if (j == 0 || KMAX == 1) left = lv0;
+            else if (j == 1 || KMAX == 2) left = lv1;
+            else if (j == 2 || KMAX == 3) left = lv2;
+            else left = lv3;
             cur = b2b_node(left, cur);                   // merkle.rs:52-54: H(left || right)
         }
-        switch (j) {
-        case 0: lv0 = cur; break;
-        case 1: lv1 = cur; break;
-        case 2: lv2 = cur; break;
-        default: lv3 = cur; break;
+        if (j < K) {                                     // j == K: the subtree's root, nothing waits for it
+            if (j == 0 || KMAX == 1) lv0 = cur;
+            else if (j == 1 || KMAX == 2) lv1 = cur;
+            else if (j == 2 || KMAX == 3) lv2 = cur;
+            else lv3 = cur;
         }
     }
     return cur;
@@ -78,22 +78,26 @@ __global__ __launch_bounds__(256) void k_hash_leaves(const fp* __restrict__ elem
     }
 }
 
+// KMAX = 3 for K <= 3 (every launch of the commit), 4 only for the K = 4 that sh_dev_merkle_subtrees also accepts: one stack level
+// fewer is 16 VGPRs fewer, and with <= 128 a SIMD holds four of these waves instead of three.
+template <int KMAX>
 __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_leaf_subtree(const fp* __restrict__ elems, digest64* __restrict__ out, size_t n_out, uint32_t K) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     const fp* base = elems + (i << K);
-    digest64 d = subtree_reduce(K, [&](uint32_t q) {
+    digest64 d = subtree_reduce<KMAX>(K, [&](uint32_t q) {
         fp e = base[q];
         return b2b_leaf(fp_lo64(e), fp_hi64(e));
     });
     store_digest(out + i, d);
 }
 
+template <int KMAX>
 __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_node_subtree(const digest64* __restrict__ in, digest64* __restrict__ out, size_t n_out, uint32_t K) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     const digest64* base = in + (i << K);
-    digest64 d = subtree_reduce(K, [&](uint32_t q) { return load_digest(base + q); });
+    digest64 d = subtree_reduce<KMAX>(K, [&](uint32_t q) { return load_digest(base + q); });
     store_digest(out + i, d);
 }
 
@@ -157,6 +161,7 @@ __device__ __forceinline__ fp load_tw(const fp* __restrict__ tw, uint32_t log_n,
 // Batched form: B codewords of length 2*half back to back; lane i owns outputs [i<<K, (i+1)<<K) of the
 // concatenated folded codewords (2^K <= half, so a lane never straddles two codewords).  The per-codeword
 // constant c0 = alpha/(2*offset) comes from `c0_arr[b]` (device, Montgomery form) or, when null, `c0_single`.
+template <int KMAX>
 __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const fp* __restrict__ cw, uint32_t log_half, const fp* __restrict__ c0_arr,
                                                            fp c0_single, const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
                                                            fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out, uint32_t K,
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const 
     const fp c0_mont = c0_arr ? c0_arr[b] : c0_single;
     const fp* lo = cw + (b << (log_half + 1)) + w0;
     const fp* hi = lo + half;
-    digest64 d = subtree_reduce(K, [&](uint32_t q) {
+    digest64 d = subtree_reduce<KMAX>(K, [&](uint32_t q) {
         fp t = mont_mul(load_tw(tw_inv, log_n_table, (w0 + q) << tw_shift), c0_mont);
         fp v = fold_one(lo[q], hi[q], t);
         out[j0 + q] = v;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const 
 // l, 64+l, ...: one coalesced 1 KB read of each half, the fold, one coalesced 1 KB write of the result per step — and parks
 // the results in LDS (rows of 8 padded to 9 so the later per-lane reads spread over the banks); then every lane hashes its
 // own 8 consecutive results out of LDS.  9.2 KB of LDS per wave, so the kernel runs as many waves as its registers allow
-// (3 per SIMD); the first staged form kept both input halves in LDS (18.4 KB per wave), ran 2 waves per SIMD and was ~10 %
+// (4 per SIMD); the first staged form kept both input halves in LDS (18.4 KB per wave), ran 2 waves per SIMD and was ~10 %
 // slower for it.
 #define STAGE_ROW 9
 #define STAGE_WAVE_ELEMS (64 * STAGE_ROW)
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_leaf_subtree_staged(const fp* _
         mine[e + (e >> 3)] = v;
     }
     __syncthreads();
-    digest64 d = subtree_reduce(3, [&](uint32_t q) {
+    digest64 d = subtree_reduce<3>(3, [&](uint32_t q) {
         const fp v = mine[lane * STAGE_ROW + q];
         return b2b_leaf(fp_lo64(v), fp_hi64(v));
     });
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_leaf_subtree_staged(cons
         mine[e + (e >> 3)] = base[e];
     }
     __syncthreads();
-    digest64 d = subtree_reduce(3, [&](uint32_t q) {
+    digest64 d = subtree_reduce<3>(3, [&](uint32_t q) {
         fp e = mine[lane * STAGE_ROW + q];
         return b2b_leaf(fp_lo64(e), fp_hi64(e));
     });
@@ -261,13 +266,15 @@ hipError_t launch_leaf_subtree(const fp* elems, digest64* out, size_t n_out, uin
         hipLaunchKernelGGL(k_leaf_subtree_staged, dim3((unsigned)(n_out >> 8)), dim3(256), 0, s, elems, out, n_out);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_leaf_subtree, dim3(grid_for(n_out, 256)), dim3(256), 0, s, elems, out, n_out, K);
+    if (K <= 3) hipLaunchKernelGGL(k_leaf_subtree<3>, dim3(grid_for(n_out, 256)), dim3(256), 0, s, elems, out, n_out, K);
+    else hipLaunchKernelGGL(k_leaf_subtree<4>, dim3(grid_for(n_out, 256)), dim3(256), 0, s, elems, out, n_out, K);
     return hipGetLastError();
 }
 hipError_t launch_node_subtree(const digest64* in, digest64* out, size_t n_out, uint32_t K, hipStream_t s) {
     if (!n_out) return hipSuccess;
     if (K < 1 || K > SUBTREE_KMAX) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_node_subtree, dim3(grid_for(n_out, 256)), dim3(256), 0, s, in, out, n_out, K);
+    if (K <= 3) hipLaunchKernelGGL(k_node_subtree<3>, dim3(grid_for(n_out, 256)), dim3(256), 0, s, in, out, n_out, K);
+    else hipLaunchKernelGGL(k_node_subtree<4>, dim3(grid_for(n_out, 256)), dim3(256), 0, s, in, out, n_out, K);
     return hipGetLastError();
 }
 hipError_t launch_merkle_tail(const digest64* in, digest64* root, size_t n_in, hipStream_t s) {
@@ -294,7 +301,9 @@ hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* 
                            log_n_table, tw_shift, out, digests, n_out, d_abort);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_fold_leaf_subtree, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
-                       log_n_table, tw_shift, out, digests, n_out, K, d_abort);
+    if (K <= 3) hipLaunchKernelGGL(k_fold_leaf_subtree<3>, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
+                                   log_n_table, tw_shift, out, digests, n_out, K, d_abort);
+    else hipLaunchKernelGGL(k_fold_leaf_subtree<4>, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
+                            log_n_table, tw_shift, out, digests, n_out, K, d_abort);
     return hipGetLastError();
 }
