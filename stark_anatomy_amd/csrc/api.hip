@@ -55,6 +55,31 @@ int32_t get_twiddles(sh_ctx* c, uint32_t log_n, bool inverse, const fp** out) {
     return SH_OK;
 }
 
+// Direct tables of the inter-pass twiddles (kernels.h: NttPassTables) for the passes whose table is small enough to stay in L2
+// across the tiles that share it (m <= 2^STARK_HIP_NTT_PASS_TW_LOG elements, default 2^20 = 16 MiB): every pass but the first
+// of a large transform.  Built once per (size, direction, pass) and cached with the context.
+int32_t get_pass_tables(sh_ctx* c, const NttPlan& plan, bool inverse, const fp* tw, NttPassTables* out) {
+    static const uint32_t max_log = [] { const char* e = getenv("STARK_HIP_NTT_PASS_TW_LOG"); const int v = e ? atoi(e) : 20; return (uint32_t)(v < 0 ? 0 : v > 26 ? 26 : v); }();
+    uint32_t consumed = 0;
+    for (uint32_t pi = 0; pi < NTT_MAX_PASSES; ++pi) out->t[pi] = nullptr;
+    for (uint32_t pi = 0; pi + 1 < plan.num_passes; ++pi) {
+        const uint32_t log_m = plan.log_n - consumed;
+        consumed += plan.bits[pi];
+        if (log_m > max_log) continue;
+        const uint32_t key = (plan.log_n * 2 + (inverse ? 1 : 0)) * NTT_MAX_PASSES + pi;
+        auto it = c->ptw_cache.find(key);
+        if (it == c->ptw_cache.end()) {
+            fp* d = nullptr;
+            HIPCHK(hipMalloc(&d, ((size_t)1 << log_m) * sizeof(fp)));
+            const hipError_t e = launch_pass_twiddles(d, tw, plan.log_n, log_m, plan.bits[pi], c->stream);
+            if (e != hipSuccess) { (void)hipFree(d); return sh_failf(SH_EHIP, "pass twiddle table: %s", hipGetErrorString(e)); }
+            it = c->ptw_cache.emplace(key, d).first;
+        }
+        out->t[pi] = it->second;
+    }
+    return SH_OK;
+}
+
 extern "C" {
 
 const char* sh_last_error(void) { return g_last_error.c_str(); }
@@ -104,6 +129,7 @@ int32_t sh_ctx_destroy(sh_ctx* c) {
     delete c->pool;
     if (getenv("STARK_HIP_DEBUG")) fprintf(stderr, "[stark_hip] ctx %p: mailbox roots %u, fallbacks %llu\n", (void*)c, c->mail_seq, (unsigned long long)c->mail_fallbacks);
     for (auto& kv : c->tw_cache) (void)hipFree(kv.second);
+    for (auto& kv : c->ptw_cache) (void)hipFree(kv.second);
     for (int i = 0; i < NUM_SCRATCH; ++i) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_root) (void)hipFree(c->d_root);
@@ -194,7 +220,9 @@ int32_t dev_ntt(sh_ctx* c, fp* d_data, uint32_t log_n, bool inverse, size_t batc
     ntt_make_plan(log_n, &plan);
     fp scale = fp_mont_one();
     if (inverse) scale = fp_to_mont(fp_inv(fp_from_u64x2((uint64_t)1 << log_n, 0)));
-    HIPCHK(launch_ntt(plan, d_data, (fp*)scratch, tw, scale, inverse, batch, c->stream));
+    NttPassTables ptab;
+    SHCHK(get_pass_tables(c, plan, inverse, tw, &ptab));
+    HIPCHK(launch_ntt(plan, d_data, (fp*)scratch, tw, scale, inverse, batch, c->stream, nullptr, &ptab));
     return SH_OK;
 }
 
@@ -304,7 +332,9 @@ int32_t sh_dev_coset_lde(sh_ctx* c, const uint64_t* d_coeffs, uint32_t log_n, ui
     HIPCHK(launch_pow_table(pow_chunk, sh.chunks, pow2k(sh.log_cols), c->stream));
     HIPCHK(launch_pow_table(pow_col, sh.cols, pow2k(0), c->stream));
     const NttLdeFuse fuse{(const fp*)d_coeffs, log_expansion, pow_row, pow_chunk, pow_col};
-    HIPCHK(launch_ntt(plan, (fp*)d_out, (fp*)scratch, tw, fp_mont_one(), false, 1, c->stream, &fuse));
+    NttPassTables ptab;
+    SHCHK(get_pass_tables(c, plan, false, tw, &ptab));
+    HIPCHK(launch_ntt(plan, (fp*)d_out, (fp*)scratch, tw, fp_mont_one(), false, 1, c->stream, &fuse, &ptab));
     return SH_OK;
 }
 int32_t sh_coset_lde(sh_ctx* c, const uint64_t* coeffs, uint32_t log_n, uint32_t log_expansion, const uint64_t offset[2], uint64_t* out) {

@@ -119,6 +119,7 @@ struct sh_ctx {
     bool mail_pending = false;                   // the root of the last reduction arrives through the mailbox
     uint64_t mail_fallbacks = 0;
     std::map<uint32_t, fp*> tw_cache;            // key = log_n*2 + inverse
+    std::map<uint32_t, fp*> ptw_cache;           // direct inter-pass twiddle tables: key = (log_n*2 + inverse)*NTT_MAX_PASSES + pass
     uint8_t* h_batch = nullptr;                  // pinned, device-mapped staging for batched commits: roots (B*64) | c0 (B*16)
     uint8_t* d_hbatch = nullptr;                 // device view of h_batch
     size_t h_batch_bytes = 0;
@@ -154,6 +155,7 @@ static inline fp host_root_of_unity(uint32_t log_n) {
 // api.hip
 int32_t ensure_scratch(sh_ctx* c, int slot, size_t bytes, void** out);
 int32_t get_twiddles(sh_ctx* c, uint32_t log_n, bool inverse, const fp** out);
+int32_t get_pass_tables(sh_ctx* c, const NttPlan& plan, bool inverse, const fp* tw, NttPassTables* out);
 int32_t dev_ntt(sh_ctx* c, fp* d_data, uint32_t log_n, bool inverse, size_t batch = 1);   // natural order in and out, on the context's stream
 // api_merkle.hip
 int32_t reduce_digests(sh_ctx* c, const digest64* cur, size_t count);

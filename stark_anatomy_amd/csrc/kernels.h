@@ -63,7 +63,13 @@ struct NttLdeShape { size_t rows, chunks, cols; uint32_t log_row_stride, log_col
 struct NttLdeFuse { const fp* coeffs; uint32_t log_expansion; const fp *pow_row, *pow_chunk, *pow_col; };
 bool ntt_lde_fusable(const NttPlan& plan, uint32_t log_expansion, NttLdeShape* shape);
 hipError_t launch_pow_table(fp* out, size_t count, fp base_mont, hipStream_t s);
-hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s, const NttLdeFuse* fuse = nullptr);
+// Direct tables of a transform's inter-pass twiddles: t[pi][(k << log_cols_pi) + col] = w_m^(col·k) for the non-final pass pi
+// (m = the pass's sub-block length, col < m/R, k < R), or null: the pass then builds each twiddle from the two-level table
+// (one more multiply per element).
+struct NttPassTables { const fp* t[NTT_MAX_PASSES]; };
+hipError_t launch_pass_twiddles(fp* out, const fp* tw, uint32_t log_n, uint32_t log_m, uint32_t log_r, hipStream_t s);
+hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s, const NttLdeFuse* fuse = nullptr,
+                      const NttPassTables* ptab = nullptr);
 hipError_t launch_scale_powers(fp* data, size_t count, fp start_mont, fp base, hipStream_t s);
 hipError_t launch_twiddle_scale(fp* data, size_t rows, uint32_t log_cols, uint64_t row0, uint64_t col0, const fp* tw, uint32_t log_n, hipStream_t s);
 // out[j] = j < n ? coeffs[j]·offset^j : 0   for j < N  (coset pre-scale + zero pad, G7)

@@ -15,11 +15,10 @@
 // Butterflies are decimation-in-frequency, so rows come out bit-reversed and the reversal is
 // absorbed into the store address.  Twiddles come from a two-level table of Montgomery-form powers
 // (4096 + n/4096 entries, L2-resident): w^e = lo[e & 4095]·hi[e >> 12].
-// The NTT passes keep the plain-C mont_mul: the asm form (fp128.cuh) has a third fewer instructions but holds more registers at
-// once, k_ntt_pass goes from 64 to 79 VGPRs, and a 1024-lane workgroup then no longer fits twice on a CU — measured at 2^24:
-// 1.005 ms with the C form, 1.16 ms with the asm form, 1.14 ms with the asm form squeezed into 64 VGPRs by spilling
-// (profiles/r02_mont_mul_microbench.txt).
-#define FP_MONT_MUL_C
+// mont_mul is the asm form of fp128.cuh (a third fewer instructions).  Round 2 first kept the plain-C form here: with the asm
+// form k_ntt_pass took 79 VGPRs and a 1024-lane workgroup no longer fitted twice on a CU (1.16 ms against 1.005 at 2^24).
+// Since the last level group is a specialisation of its own (ntt_levels<S, true>) the kernel needs 60, and the asm form
+// wins: 0.95 -> 0.90 ms (-DFP_MONT_MUL_C brings the C form back).
 #include "kernels.h"
 
 struct NttPassParams {
@@ -37,6 +36,7 @@ struct NttPassParams {
     // Montgomery-form power tables: pow_row[r] = offset^(r·n/R... the row stride), pow_chunk[k] = offset^(k·C), pow_col[c] = offset^c.
     uint32_t fuse_log_e;
     const fp *pow_row, *pow_chunk, *pow_col;
+    const fp* tw_pass;            // non-final pass: direct table of its inter-pass twiddles, [k][col] (NttPassTables), or null
 };
 
 __device__ __forceinline__ fp ntt_load_tw(const fp* __restrict__ tw, uint32_t log_n, size_t e) {
@@ -49,6 +49,9 @@ __device__ __forceinline__ fp ntt_load_tw(const fp* __restrict__ tw, uint32_t lo
 #ifndef NTT_THREADS
 #define NTT_THREADS 1024
 #endif
+#ifndef NTT_TILE_LOG
+#define NTT_TILE_LOG 12               // elements per tile (log2)
+#endif
 #ifndef NTT_RADIX_LOG
 #define NTT_RADIX_LOG 2
 #endif
@@ -57,7 +60,10 @@ __device__ __forceinline__ fp ntt_load_tw(const fp* __restrict__ tw, uint32_t lo
 // round trip: a work item is the 2^S rows that differ in row bits [lo, lo+S) at one column; it is read once, takes
 // its S butterfly levels in registers and is written back to the same addresses (no barrier inside).
 // Level with pair distance 2^h multiplies the difference by w_R^(j << (log_r-1-h)), j = row mod 2^h (none for h = 0).
-template <int S>
+// LO0: the group is the last one (lo == 0), where j = 0 — a multiplication by one — for every butterfly of level h whose
+// position inside the work item is a multiple of 2^h: known at compile time and skipped (a quarter of a multiply per element
+// and pass; exact, since the operand is canonical).
+template <int S, bool LO0>
 __device__ __forceinline__ void ntt_levels(fp* __restrict__ x, const fp* __restrict__ twr, uint32_t rs, uint32_t log_r, uint32_t log_c,
                                            uint32_t lo, uint32_t T, uint32_t tid, uint32_t nthreads) {
     const uint32_t C = 1u << log_c;
@@ -76,7 +82,7 @@ __device__ __forceinline__ void ntt_levels(fp* __restrict__ x, const fp* __restr
                 const fp u = v[e], t = v[e | (1 << s)];
                 v[e] = fp_add(u, t);
                 fp d = fp_sub(u, t);
-                if (lo + s) d = mont_mul(d, twr[(r_low + ((uint32_t)(e & ((1 << s) - 1)) << lo)) << sh]);
+                if (LO0 ? (e & ((1 << s) - 1)) != 0 : true) d = mont_mul(d, twr[(r_low + ((uint32_t)(e & ((1 << s) - 1)) << lo)) << sh]);
                 v[e | (1 << s)] = d;
             }
         }
@@ -140,14 +146,15 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams p) {
     // barrier per group of levels instead of per level.
     for (uint32_t hb = p.log_r; hb > 0;) {
         const uint32_t S = hb < NTT_RADIX_LOG ? hb : NTT_RADIX_LOG, lo = hb - S;
-        switch (S) {
-            case 1: ntt_levels<1>(x, twr, rs, p.log_r, p.log_c, lo, T, tid, blockDim.x); break;
-            case 2: ntt_levels<2>(x, twr, rs, p.log_r, p.log_c, lo, T, tid, blockDim.x); break;
+        if (lo) ntt_levels<NTT_RADIX_LOG, false>(x, twr, rs, p.log_r, p.log_c, lo, T, tid, blockDim.x);      // lo > 0: a full group
+        else switch (S) {
+            case 1: ntt_levels<1, true>(x, twr, rs, p.log_r, p.log_c, 0, T, tid, blockDim.x); break;
+            case 2: ntt_levels<2, true>(x, twr, rs, p.log_r, p.log_c, 0, T, tid, blockDim.x); break;
 #if NTT_RADIX_LOG >= 3
-            case 3: ntt_levels<3>(x, twr, rs, p.log_r, p.log_c, lo, T, tid, blockDim.x); break;
+            case 3: ntt_levels<3, true>(x, twr, rs, p.log_r, p.log_c, 0, T, tid, blockDim.x); break;
 #endif
 #if NTT_RADIX_LOG >= 4
-            case 4: ntt_levels<4>(x, twr, rs, p.log_r, p.log_c, lo, T, tid, blockDim.x); break;
+            case 4: ntt_levels<4, true>(x, twr, rs, p.log_r, p.log_c, 0, T, tid, blockDim.x); break;
 #endif
         }
         __syncthreads();
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams p) {
             const uint32_t k = __brev(r) >> (32 - p.log_r);
             fp v = x[r * rs + c];
             const size_t e = ((size_t)(colbase + c) * k) << tw_shift;
-            v = mont_mul(v, ntt_load_tw(p.tw, p.log_n, e));
+            v = mont_mul(v, p.tw_pass ? p.tw_pass[(size_t)k * row_stride_in + colbase + c] : ntt_load_tw(p.tw, p.log_n, e));
             out[base + (size_t)k * row_stride_in + c] = v;
         }
     } else {
@@ -229,7 +236,7 @@ hipError_t launch_pow_table(fp* out, size_t count, fp base_mont, hipStream_t s) 
 bool ntt_lde_fusable(const NttPlan& plan, uint32_t log_expansion, NttLdeShape* shape) {
     if (plan.num_passes < 2 || log_expansion == 0 || log_expansion > plan.bits[0]) return false;
     const uint32_t log_r = plan.bits[0], log_mp = plan.log_n - log_r;
-    const uint32_t log_c = (12 - log_r) < log_mp ? (12 - log_r) : log_mp;
+    const uint32_t log_c = (NTT_TILE_LOG - log_r) < log_mp ? (NTT_TILE_LOG - log_r) : log_mp;
     shape->rows = (size_t)1 << (log_r - log_expansion);
     shape->chunks = (size_t)1 << (log_mp - log_c);
     shape->cols = (size_t)1 << log_c;
@@ -238,7 +245,23 @@ bool ntt_lde_fusable(const NttPlan& plan, uint32_t log_expansion, NttLdeShape* s
     return true;
 }
 
-hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s, const NttLdeFuse* fuse) {
+// out[(k << (log_m - log_r)) + col] = w_m^(col·k), k < 2^log_r, col < 2^(log_m - log_r): the inter-pass twiddles of the pass
+// that works on sub-blocks of m = 2^log_m elements, in the order its tiles read them (col fastest: coalesced)
+__global__ __launch_bounds__(256) void k_pass_twiddles(fp* __restrict__ out, const fp* __restrict__ tw, uint32_t log_n, uint32_t log_m, uint32_t log_r) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> log_m) return;
+    const uint32_t log_mp = log_m - log_r;
+    const size_t k = i >> log_mp, col = i & (((size_t)1 << log_mp) - 1);
+    out[i] = ntt_load_tw(tw, log_n, (col * k) << (log_n - log_m));
+}
+hipError_t launch_pass_twiddles(fp* out, const fp* tw, uint32_t log_n, uint32_t log_m, uint32_t log_r, hipStream_t s) {
+    if (log_m > log_n || log_r > log_m || log_m > 30) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pass_twiddles, dim3((unsigned)((((size_t)1 << log_m) + 255) / 256)), dim3(256), 0, s, out, tw, log_n, log_m, log_r);
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s, const NttLdeFuse* fuse,
+                      const NttPassTables* ptab) {
     static bool attr_set[64] = {};             // per device: the attribute belongs to the function on the current device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -261,7 +284,8 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         if (!is_final) {
             p.log_m = log_n - consumed;
             const uint32_t log_mp = p.log_m - p.log_r;
-            p.log_c = (12 - p.log_r) < log_mp ? (12 - p.log_r) : log_mp;
+            p.log_c = (NTT_TILE_LOG - p.log_r) < log_mp ? (NTT_TILE_LOG - p.log_r) : log_mp;
+            p.tw_pass = ptab ? ptab->t[pi] : nullptr;
             p.in = data;                                               // non-final passes work in place on `data` ...
             p.out = (pi + 2 == P) ? scratch : data;                    // ... except the last one, which lands in scratch
             if (pi == 0 && fuse) {                                     // coset LDE: the first pass reads the coefficients themselves
@@ -271,7 +295,7 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
             }
         } else {
             p.log_r0 = (P >= 2) ? plan.bits[0] : 0;
-            p.log_c = (12 - p.log_r) < p.log_r0 ? (12 - p.log_r) : p.log_r0;
+            p.log_c = (NTT_TILE_LOG - p.log_r) < p.log_r0 ? (NTT_TILE_LOG - p.log_r) : p.log_r0;
             p.num_mid = (P >= 2) ? P - 2 : 0;
             for (uint32_t q = 0; q < p.num_mid; ++q) p.mid_bits[q] = plan.bits[1 + q];
             p.apply_scale = apply_scale ? 1 : 0;
