@@ -46,6 +46,19 @@ __global__ void k_chain(uint64_t* out, int iters) {
     if (a == 0x12345 && b == 77 && w == 5 && e == 1 && f == 2 && w2 == 9) out[1000] = a + lds_dummy[3];
 }
 
+// Does a wave64 whose upper lanes are switched off issue faster?  The dependent v_xor chain with only lanes < `lanes` active.
+__global__ void k_chain_masked(uint64_t* out, int iters, uint32_t lanes) {
+    uint32_t a = threadIdx.x * 2654435761u + 1, c = 0x85ebca6bu;
+    uint64_t t0 = 0, r0 = 0, t1 = 0, r1 = 0;
+    if ((threadIdx.x & 63) < lanes) {
+        t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+        for (int it = 0; it < iters; ++it) asm volatile(R64("v_xor_b32 %0, %0, %1\n") : "+v"(a) : "v"(c));
+        t1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = t1 - t0; out[2 * blockIdx.x + 1] = r1 - r0; }
+    if (a == 0x12345) out[1000] = a;
+}
+
 // `chain` dependent compressions per quad: the digest goes back into the quad's message slot and is hashed again.
 template <int ILP>
 __global__ __launch_bounds__(512) void k_quad_chain(uint64_t* out, int chain) {
@@ -105,6 +118,11 @@ int main() {
         chain<13>("v_lshl_add_u64 x2 independent", blocks, threads, 1);
         chain<14>("v_xor_b32_dpp x4 independent", blocks, threads, 1);
         chain<15>("ds_read_b64 x2 (+wait per 128)", blocks, threads, 2);
+    }
+    for (uint32_t lanes : {64u, 32u, 16u, 4u}) {
+        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k_chain_masked, dim3(1), dim3(64), 0, 0, g_buf, 400, lanes);
+        char nm[64]; snprintf(nm, sizeof nm, "v_xor_b32 dependent, %u lanes on", lanes);
+        report(nm, 1, 64, 400.0 * 64, "instr");
     }
     const int n = 64;
     for (int threads : {64, 128, 256, 512}) {
