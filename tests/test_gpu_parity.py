@@ -209,6 +209,35 @@ def test_ntt_large_properties(ctx):
     d.free()
 
 
+def test_ntt_without_direct_pass_tables(ctx):
+    """The inter-pass twiddles come from direct per-pass tables by default (api.hip: get_pass_tables); with
+    STARK_HIP_NTT_PASS_TW_LOG=0 every pass builds them from the two-level table instead.  The switch is read once per
+    process, so the table-less path runs in a child process; both must give the same bits (and the in-process one is
+    compared with the oracle elsewhere)."""
+    import os, subprocess, sys
+    code = ("import hashlib, numpy as np, stark_anatomy_amd as sa\n"
+            "from oracle import coracle as co\n"
+            "c = sa.Context(0)\n"
+            "for log_n in (9, 13, 16, 20, 22):\n"
+            "    x = co.splitmix_elems(700 + log_n, 1 << log_n)\n"
+            "    y = sa.ntt(x, ctx=c); z = sa.intt(x, ctx=c)\n"
+            "    l = sa.coset_lde(x, 2, sa.GENERATOR, ctx=c) if log_n <= 20 else y\n"
+            "    print(log_n, *(hashlib.sha256(np.ascontiguousarray(a, dtype='<u8').tobytes()).hexdigest() for a in (y, z, l)))\n"
+            "c.close()\n")
+    env = dict(os.environ, STARK_HIP_NTT_PASS_TW_LOG="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [ln.split() for ln in out.stdout.strip().splitlines()]
+    assert [int(r[0]) for r in rows] == [9, 13, 16, 20, 22]
+    for r in rows:
+        log_n = int(r[0])
+        x = co.splitmix_elems(700 + log_n, 1 << log_n)
+        y = sa.ntt(x, ctx=ctx); z = sa.intt(x, ctx=ctx)
+        l = sa.coset_lde(x, 2, sa.GENERATOR, ctx=ctx) if log_n <= 20 else y
+        assert [digest(y), digest(z), digest(l)] == r[1:], log_n
+
+
 def test_lde_golden_and_oracle(ctx, golden):
     for e in golden("lde_vectors.json"):
         c = co.splitmix_elems(e["seed"], 1 << e["log_n"])
