@@ -267,6 +267,13 @@ int32_t sh_fri_verify(sh_proofstream* ps, size_t N, const sh_fri_params* prm, in
     const uint32_t t = prm->num_colinearity_tests, log_N = ilog2(N);
     const uint32_t R = sh_fri_num_rounds(N, prm->expansion, t);
     auto reject = [&](const char* why) { sh_fail(SH_OK, why); return SH_OK; };
+    const bool dbg = getenv("STARK_HIP_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_field = 0, t_parse = 0, t_hash = 0, t_head = 0;
+    const double t_begin = now();
+    struct Report { bool on; double *f, *p, *h, *hd; double t0; std::function<double()> clk;
+                    ~Report() { if (on) fprintf(stderr, "[stark_hip] verify: %.0f us total: roots/last codeword/low degree %.0f, colinearity (field) %.0f, path parsing %.0f, path hashing %.0f\n", clk() - t0, *hd, *f, *p, *h); } }
+        report{dbg, &t_field, &t_parse, &t_hash, &t_head, t_begin, now};
     const uint8_t* js; size_t jl;
     std::vector<uint8_t> roots((size_t)R * 64);
     std::vector<fp> alphas;
@@ -280,7 +287,7 @@ int32_t sh_fri_verify(sh_proofstream* ps, size_t N, const sh_fri_params* prm, in
         }
     }
     std::vector<uint64_t> lastw;
-    if (sh_proofstream_pull(ps, &js, &jl) != SH_OK || !host_parse_elems(js, jl, "Codeword", &lastw)) return reject("verify: expected the last Codeword item");
+    if (!host_ps_pull_elems(ps, "Codeword", &lastw)) return reject("verify: expected the last Codeword item");
     const size_t L_last = N >> (R ? R - 1 : 0);
     if (lastw.size() != 2 * L_last) return reject("verify: last codeword has the wrong length");
     std::vector<fp> last(L_last);
@@ -302,6 +309,7 @@ int32_t sh_fri_verify(sh_proofstream* ps, size_t N, const sh_fri_params* prm, in
         for (size_t j = max_coeffs; j < L_last; ++j) if (!fp_is_zero(co[j])) return reject("verify: last codeword is not of low degree");
     }
     if (R < 2) { *accepted = 1; return SH_OK; }
+    t_head = now() - t_begin;
     uint8_t seed[32];
     SHCHK(sh_proofstream_verifier_fiat_shamir(ps, seed));
     std::vector<uint64_t> top;
@@ -314,8 +322,9 @@ int32_t sh_fri_verify(sh_proofstream* ps, size_t N, const sh_fri_params* prm, in
         const size_t L = N >> r;
         const uint32_t d0 = ilog2(L), d1 = d0 - 1;
         std::vector<std::vector<uint64_t>> abc(t);
+        const double tf0 = now();
         for (uint32_t s_ = 0; s_ < t; ++s_) {
-            if (sh_proofstream_pull(ps, &js, &jl) != SH_OK || !host_parse_elems(js, jl, "Leaves", &abc[s_]) || abc[s_].size() != 6) return reject("verify: expected a Leaves item with three values");
+            if (!host_ps_pull_elems(ps, "Leaves", &abc[s_]) || abc[s_].size() != 6) return reject("verify: expected a Leaves item with three values");
             const fp ay = fp_from_u64x2(abc[s_][0], abc[s_][1]), by = fp_from_u64x2(abc[s_][2], abc[s_][3]), cy = fp_from_u64x2(abc[s_][4], abc[s_][5]);
             if (!fp_is_canonical(ay) || !fp_is_canonical(by) || !fp_is_canonical(cy)) return reject("verify: non-canonical value in a Leaves item");
             // colinearity of (ax, ay), (-ax, by), (alpha, cy), ax = off_r·w_r^a  <=>  cy = fold(ay, by) (G4)
@@ -325,19 +334,24 @@ int32_t sh_fri_verify(sh_proofstream* ps, size_t N, const sh_fri_params* prm, in
             const fp want = fp_mul(inv2, fp_add(fp_mul(fp_add(fp_one(), q), ay), fp_mul(fp_sub(fp_one(), q), by)));
             if (!fp_eq(want, cy)) return reject("verify: colinearity check failed");
         }
+        t_field += now() - tf0;
         for (uint32_t s_ = 0; s_ < t; ++s_) {
             const uint64_t a = top[s_] % (L / 2);
             const uint64_t where[3] = {a, a + L / 2, a};
             for (int k = 0; k < 3; ++k) {
                 std::vector<uint8_t> path;
                 const uint32_t depth = k < 2 ? d0 : d1;
-                if (sh_proofstream_pull(ps, &js, &jl) != SH_OK || !host_parse_path(js, jl, &path) || path.size() != (size_t)depth * 64) return reject("verify: expected a Path item of the tree's depth");
+                const double tp0 = now();
+                if (!host_ps_pull_path(ps, &path) || path.size() != (size_t)depth * 64) return reject("verify: expected a Path item of the tree's depth");
+                const double tp1 = now();
+                t_parse += tp1 - tp0;
                 uint8_t le[16], leaf[64];
                 memcpy(le, &abc[s_][2 * k], 8); memcpy(le + 8, &abc[s_][2 * k + 1], 8);
                 host_blake2b512(le, 16, leaf);
                 int32_t ok = 0;
                 SHCHK(sh_merkle_verify(roots.data() + 64 * (size_t)(r + (k == 2 ? 1 : 0)), leaf, path.data(), depth, where[k], &ok));
                 if (!ok) return reject("verify: Merkle authentication path check failed");
+                t_hash += now() - tp1;
             }
         }
         off_r = fp_mul(off_r, off_r); w_r = fp_mul(w_r, w_r);

@@ -304,6 +304,15 @@ struct JsonScan {
             else {
                 ok = false;
                 for (;;) {
+                    // a run of plain unsigned integers (digests, field elements: most of a proof's bytes) is copied as it
+                    // stands; anything else (sign, fraction, exponent, leading zero, nesting) takes the general path
+                    while (p < end && *p >= '1' && *p <= '9') {
+                        const uint8_t* s0 = p;
+                        while (p < end && *p >= '0' && *p <= '9') ++p;
+                        if (p < end && *p == ',' && p + 1 < end && p[1] >= '1' && p[1] <= '9') { ++p; out.append((const char*)s0, (size_t)(p - s0)); continue; }
+                        p = s0;
+                        break;
+                    }
                     if (!value(out)) break;
                     ws(); if (p >= end) break;
                     if (*p == ',') { ++p; out.push_back(','); continue; }
@@ -321,6 +330,10 @@ struct JsonScan {
     }
 };
 }  // namespace
+
+// deserialize's fast path (defined below, next to the typed item parsers): a Path / Leaves / Codeword item in exactly the
+// text that materialize() writes is taken over in raw form; false = not such an item, nothing consumed.
+static bool read_typed_item_raw(const uint8_t*& p, const uint8_t* end, std::string* raw);
 
 // Nothing unwinds through the C ABI: an allocation failure inside an entry point comes back as SH_ENOMEM.
 #define SH_GUARD_BEGIN try {
@@ -459,7 +472,12 @@ int32_t sh_proofstream_deserialize(const uint8_t* bytes, size_t len, sh_proofstr
     else {
         for (;;) {
             std::string item;
-            if (!sc.value(item)) break;
+            sc.ws();
+            // The bulk of a proof (authentication paths, leaf values, the last codeword) in canonical text is kept raw, as the
+            // prover's own pushes keep it: serialising it again gives the same bytes, and the verifier reads it without parsing
+            // the text a second time.  Everything else — other items, the same items with white space or non-canonical numbers —
+            // is validated and compacted by the general scanner and kept as text.
+            if (!read_typed_item_raw(sc.p, sc.end, &item) && !sc.value(item)) break;
             ps->items.push_back(std::move(item));
             sc.ws();
             if (sc.p >= sc.end) break;
@@ -513,23 +531,38 @@ struct ItemParse {
     bool u128(unsigned __int128* v) {                         // bare decimal, no sign, no leading zeros except "0", < 2^128
         if (p >= end || *p < '0' || *p > '9') return false;
         if (*p == '0' && p + 1 < end && p[1] >= '0' && p[1] <= '9') return false;
+        // 38 digits cannot overflow (10^38 < 2^128); only a 39th needs the check — no 128-bit division per digit
         unsigned __int128 acc = 0;
-        const unsigned __int128 lim = ~(unsigned __int128)0;
+        int digits = 0;
         while (p < end && *p >= '0' && *p <= '9') {
             const unsigned d = (unsigned)(*p - '0');
-            if (acc > (lim - d) / 10) return false;
+            if (++digits > 39) return false;
+            if (digits == 39) {
+                const unsigned __int128 lim = ~(unsigned __int128)0;
+                if (acc > lim / 10 || (acc == lim / 10 && d > (unsigned)(lim % 10))) return false;
+            }
             acc = acc * 10 + d; ++p;
         }
         *v = acc;
         return true;
     }
+    bool byte(uint8_t* v) {                                   // the same grammar for a value <= 255: at most three digits
+        if (p >= end || *p < '0' || *p > '9') return false;
+        unsigned acc = (unsigned)(*p++ - '0');
+        if (acc == 0) { if (p < end && *p >= '0' && *p <= '9') return false; *v = 0; return true; }
+        if (p < end && *p >= '0' && *p <= '9') { acc = acc * 10 + (unsigned)(*p++ - '0');
+            if (p < end && *p >= '0' && *p <= '9') { acc = acc * 10 + (unsigned)(*p++ - '0');
+                if (p < end && *p >= '0' && *p <= '9') return false; } }
+        if (acc > 255) return false;
+        *v = (uint8_t)acc;
+        return true;
+    }
     bool hash(uint8_t out[64]) {                              // {"inner":[b0,...,b63]}
         if (!lit("{\"inner\":[")) return false;
         for (int i = 0; i < 64; ++i) {
-            if (i && !lit(",")) return false;
-            unsigned __int128 v;
-            if (!u128(&v) || v > 255) return false;
-            out[i] = (uint8_t)v;
+            if (p < end && *p == ',') { if (!i) return false; ++p; }
+            else if (i) return false;
+            if (!byte(out + i)) return false;
         }
         return lit("]}");
     }
@@ -565,4 +598,64 @@ bool host_parse_path(const uint8_t* json, size_t len, std::vector<uint8_t>* out)
         if (ip.lit(",")) continue;
         return ip.lit("]}") && ip.p == ip.end;
     }
+}
+
+// Typed pulls for the verifier (internal): an item that is still raw is handed over as it is, one that is text is parsed.
+// false: no item left, or not an item of that type.
+bool host_ps_pull_path(sh_proofstream* ps, std::vector<uint8_t>* out) {
+    if (ps->read_index >= ps->items.size()) return false;
+    const std::string& it = ps->items[ps->read_index++];
+    if (!it.empty() && it[0] == LAZY_PATH) { out->assign((const uint8_t*)it.data() + 1, (const uint8_t*)it.data() + it.size()); return true; }
+    if (!it.empty() && (it[0] == LAZY_CODEWORD || it[0] == LAZY_LEAVES)) return false;
+    return host_parse_path((const uint8_t*)it.data(), it.size(), out);
+}
+bool host_ps_pull_elems(sh_proofstream* ps, const char* tag, std::vector<uint64_t>* out) {
+    if (ps->read_index >= ps->items.size()) return false;
+    const std::string& it = ps->items[ps->read_index++];
+    const char want = strcmp(tag, "Leaves") == 0 ? LAZY_LEAVES : strcmp(tag, "Codeword") == 0 ? LAZY_CODEWORD : 0;
+    if (!it.empty() && (it[0] == LAZY_PATH || it[0] == LAZY_CODEWORD || it[0] == LAZY_LEAVES)) {
+        if (it[0] != want) return false;
+        out->resize((it.size() - 1) / 8);
+        if (!out->empty()) memcpy(out->data(), it.data() + 1, out->size() * 8);
+        return true;
+    }
+    return host_parse_elems((const uint8_t*)it.data(), it.size(), tag, out);
+}
+
+static bool read_typed_item_raw(const uint8_t*& p, const uint8_t* end, std::string* out) {
+    ItemParse ip{p, end};
+    std::string buf, *raw = &buf;                      // `out` is touched only on success
+    if (ip.lit("{\"Path\":[")) {
+        raw->assign(1, LAZY_PATH);
+        if (!ip.lit("]")) {
+            for (;;) {
+                uint8_t h[64];
+                if (!ip.hash(h)) return false;
+                raw->append((const char*)h, 64);
+                if (ip.lit(",")) continue;
+                if (!ip.lit("]")) return false;
+                break;
+            }
+        }
+    } else {
+        const bool leaves = ip.lit("{\"Leaves\":[");
+        if (!leaves && !ip.lit("{\"Codeword\":[")) return false;
+        raw->assign(1, leaves ? LAZY_LEAVES : LAZY_CODEWORD);
+        if (!ip.lit("]")) {
+            for (;;) {
+                unsigned __int128 v;
+                if (!ip.u128(&v)) return false;
+                const uint64_t w[2] = {(uint64_t)v, (uint64_t)(v >> 64)};
+                raw->append((const char*)w, 16);
+                if (ip.lit(",")) continue;
+                if (!ip.lit("]")) return false;
+                break;
+            }
+        }
+    }
+    if (!ip.lit("}")) return false;
+    if (ip.p < end && *ip.p != ',' && *ip.p != ']' && *ip.p != ' ' && *ip.p != '\n' && *ip.p != '\t' && *ip.p != '\r') return false;
+    p = ip.p;
+    *out = std::move(buf);
+    return true;
 }
