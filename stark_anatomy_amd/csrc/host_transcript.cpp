@@ -390,9 +390,9 @@ int32_t sh_proofstream_push_merkle_root(sh_proofstream* ps, const uint8_t root[6
     char buf[24 + 64 * 4 + 4];
     size_t o = 24;
     memcpy(buf, "{\"MerkleRoot\":{\"inner\":[", 24);
-    for (int i = 0; i < 64; ++i) { if (i) buf[o++] = ','; o += put_u64_dec(buf + o, root[i]); }
-    memcpy(buf + o, "]}}", 3);
-    ps->items.emplace_back(buf, o + 3);
+    for (int i = 0; i < 64; ++i) { memcpy(buf + o, BYTE_DEC.txt[root[i]], 4); o += BYTE_DEC.len[root[i]] + 1; }   // "v," per byte: one 4-byte copy
+    memcpy(buf + o - 1, "]}}", 3);                                                                                 // the last comma becomes the bracket
+    ps->items.emplace_back(buf, o + 2);
     return SH_OK;
     SH_GUARD_END("sh_proofstream_push_merkle_root")
 }
