@@ -178,6 +178,19 @@ static int32_t dev_fp_op(sh_ctx* c, int op, const uint64_t* d_a, const uint64_t*
     if (!d_a || !d_out || (needs_b && !d_b)) return sh_fail(SH_EINVAL, "field op: null pointer");
     const bool checks = (op == FPOP_DIV || op == FPOP_INV);
     if (checks) HIPCHK(hipMemsetAsync(c->d_flag, 0, 4, c->stream));
+    // A large batched inversion in three launches (field_kernels.hip): chunk products, one small inversion of those, finish —
+    // instead of every workgroup waiting ~21 us per chunk for its own single-lane inversion.
+    static const bool flat = getenv("STARK_HIP_BINV_FLAT") != nullptr;
+    static const uint32_t split_log = [] { const char* e = getenv("STARK_HIP_BINV_SPLIT_LOG"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 12 && v <= 40 ? v : 22); }();
+    const bool inv_op = (op == FPOP_DIV || op == FPOP_INV || op == FPOP_INV_MONT);
+    if (inv_op && !flat && n >= ((size_t)1 << split_log)) {
+        const size_t chunks = fp_batch_inv_chunks(n);
+        void* ext;
+        SHCHK(ensure_scratch(c, SCR_BINV, chunks * sizeof(fp), &ext));
+        HIPCHK(launch_fp_batch_inv_products(op, (const fp*)d_a, (const fp*)d_b, n, (fp*)ext, c->d_flag, c->stream));
+        HIPCHK(launch_fp_binop(op == FPOP_INV ? FPOP_INV : FPOP_INV_MONT, (const fp*)ext, nullptr, (fp*)ext, chunks, c->d_flag, c->stream));
+        HIPCHK(launch_fp_batch_inv_finish(op, (const fp*)d_a, (const fp*)d_b, (fp*)d_out, n, (fp*)ext, c->d_flag, c->stream));
+    } else
     HIPCHK(launch_fp_binop(op, (const fp*)d_a, (const fp*)d_b, (fp*)d_out, n, c->d_flag, c->stream));
     if (checks) {
         HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));

@@ -101,9 +101,9 @@ class SpinPool {
 };
 
 // ------------------------------------------------------------------ context
-#define NUM_SCRATCH 15
+#define NUM_SCRATCH 16
 enum { SCR_IO_A = 0, SCR_IO_B = 1, SCR_IO_C = 2, SCR_WORK = 3, SCR_DIG_A = 4, SCR_DIG_B = 5, SCR_ROOTS = 6, SCR_C0 = 7,
-       SCR_ARENA = 8, SCR_LEVELS = 9, SCR_IDX = 10, SCR_PATHS = 11, SCR_POLY_A = 12, SCR_POLY_B = 13, SCR_LDE_TAB = 14 };
+       SCR_ARENA = 8, SCR_LEVELS = 9, SCR_IDX = 10, SCR_PATHS = 11, SCR_POLY_A = 12, SCR_POLY_B = 13, SCR_LDE_TAB = 14, SCR_BINV = 15 };
 struct sh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

@@ -12,6 +12,11 @@ enum { FPOP_ADD = 0, FPOP_SUB = 1, FPOP_MUL = 2, FPOP_DIV = 3, FPOP_INV = 4, FPO
 // inversion, one field inversion per 2048 elements).  FPOP_INV_MONT: out = 2^128 / a, the factor that makes
 // mont_mul(x, out) = x / a.
 hipError_t launch_fp_binop(int op, const fp* a, const fp* b, fp* out, size_t n, uint32_t* d_flag, hipStream_t s);
+// Split form of the batched inversion for large n (field_kernels.hip): products of the chunks of 2048 divisors into
+// ext[fp_batch_inv_chunks(n)]; the caller inverts ext in place (launch_fp_binop, FPOP_INV for op == FPOP_INV, else FPOP_INV_MONT); finish.
+size_t fp_batch_inv_chunks(size_t n);
+hipError_t launch_fp_batch_inv_products(int op, const fp* a, const fp* b, size_t n, fp* ext, uint32_t* d_flag, hipStream_t s);
+hipError_t launch_fp_batch_inv_finish(int op, const fp* a, const fp* b, fp* out, size_t n, fp* ext, uint32_t* d_flag, hipStream_t s);
 // ---- dist_kernels.hip (multi-GPU data movement) ----
 // out[c][r] = in[r][c], rows x cols elements (the pack of an all-to-all exchange when cols = P·b)
 hipError_t launch_transpose16(const fp* in, fp* out, size_t rows, size_t cols, hipStream_t s);

@@ -77,6 +77,35 @@ def test_batch_inverse_scattered_zeros(ctx):
     assert np.array_equal(sa.FieldVector(fixed[:4096], ctx).inverse().data, co.fp_batch("inv", fixed[:4096]))
 
 
+def test_batch_inverse_split_form_large(ctx):
+    """From 2^22 elements up the inversion runs as chunk products -> one small inversion -> finish (api.hip: dev_fp_op).
+    n = 2^23 + 5 with zeros in it: x · inv(x) == 1 and (a / x) · x == a at every non-zero position (GPU multiply, itself
+    checked against the oracle above), 0 and SH_EDIVZERO at the zeros, and 2^16 scattered positions bit-exact vs the oracle."""
+    n = (1 << 23) + 5
+    b = co.splitmix_elems(77, n)
+    a = co.splitmix_elems(78, n)
+    for i, e in enumerate(EDGE):
+        b[(i * 1000003) % n] = (e & (2**64 - 1), e >> 64)
+    rnd = random.Random(9)
+    zpos = np.array(sorted({0, 2047, 2048, n - 1, n - 6} | {rnd.randrange(n) for _ in range(50)}))
+    b[(b[:, 0] == 0) & (b[:, 1] == 0)] = (1, 0)
+    b[zpos] = (0, 0)
+    inv = np.empty_like(b); quo = np.empty_like(b)
+    assert lib.sh_fp_inv(ctx.handle, _u64p(b), _u64p(inv), n) == _lib.SH_EDIVZERO
+    assert lib.sh_fp_div(ctx.handle, _u64p(a), _u64p(b), _u64p(quo), n) == _lib.SH_EDIVZERO
+    assert not inv[zpos].any() and not quo[zpos].any()
+    one = np.zeros_like(b); one[:, 0] = 1
+    one[zpos] = (0, 0)
+    assert np.array_equal((sa.FieldVector(b, ctx) * sa.FieldVector(inv, ctx)).data, one)
+    exp = a.copy(); exp[zpos] = (0, 0)
+    assert np.array_equal((sa.FieldVector(quo, ctx) * sa.FieldVector(b, ctx)).data, exp)
+    pick = np.array(sorted({rnd.randrange(n) for _ in range(1 << 16)} - set(zpos.tolist())))
+    assert np.array_equal(inv[pick], co.fp_batch("inv", np.ascontiguousarray(b[pick])))
+    assert np.array_equal(quo[pick], co.fp_batch("div", np.ascontiguousarray(a[pick]), np.ascontiguousarray(b[pick])))
+    clean = b.copy(); clean[zpos] = (3, 0)
+    assert lib.sh_fp_inv(ctx.handle, _u64p(clean), _u64p(inv), n) == 0        # no zero: clean status on the same context
+
+
 # ------------------------------------------------------------------ product through the NTT
 def test_poly_mul_goldens_and_schoolbook(ctx, golden):
     for v in golden("poly_vectors.json")["mul"]:
