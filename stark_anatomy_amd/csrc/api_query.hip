@@ -323,14 +323,22 @@ int32_t sh_fri_verify(sh_proofstream* ps, size_t N, const sh_fri_params* prm, in
         const uint32_t d0 = ilog2(L), d1 = d0 - 1;
         std::vector<std::vector<uint64_t>> abc(t);
         const double tf0 = now();
+        // 1/ax for the t test points of the round with ONE field inversion (Montgomery's trick; ax = off_r·w_r^a is never zero)
+        std::vector<fp> axs(t), pre(t);
+        fp run = fp_one();
+        for (uint32_t s_ = 0; s_ < t; ++s_) {
+            axs[s_] = fp_mul(off_r, fp_pow(w_r, top[s_] % (L / 2)));
+            pre[s_] = run;
+            run = fp_mul(run, axs[s_]);
+        }
+        fp inv_run = fp_inv(run);
+        for (uint32_t s_ = t; s_-- > 0;) { const fp ai = fp_mul(inv_run, pre[s_]); inv_run = fp_mul(inv_run, axs[s_]); axs[s_] = ai; }   // axs now holds the inverses
         for (uint32_t s_ = 0; s_ < t; ++s_) {
             if (!host_ps_pull_elems(ps, "Leaves", &abc[s_]) || abc[s_].size() != 6) return reject("verify: expected a Leaves item with three values");
             const fp ay = fp_from_u64x2(abc[s_][0], abc[s_][1]), by = fp_from_u64x2(abc[s_][2], abc[s_][3]), cy = fp_from_u64x2(abc[s_][4], abc[s_][5]);
             if (!fp_is_canonical(ay) || !fp_is_canonical(by) || !fp_is_canonical(cy)) return reject("verify: non-canonical value in a Leaves item");
             // colinearity of (ax, ay), (-ax, by), (alpha, cy), ax = off_r·w_r^a  <=>  cy = fold(ay, by) (G4)
-            const uint64_t a = top[s_] % (L / 2);
-            const fp ax = fp_mul(off_r, fp_pow(w_r, a));
-            const fp q = fp_mul(alphas[r], fp_inv(ax));
+            const fp q = fp_mul(alphas[r], axs[s_]);
             const fp want = fp_mul(inv2, fp_add(fp_mul(fp_add(fp_one(), q), ay), fp_mul(fp_sub(fp_one(), q), by)));
             if (!fp_eq(want, cy)) return reject("verify: colinearity check failed");
         }
