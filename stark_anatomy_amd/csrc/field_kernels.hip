@@ -21,9 +21,9 @@ __global__ __launch_bounds__(256) void k_fp_binop(const fp* __restrict__ a, cons
 // element), FPOP_INV_MONT out = R/a (a factor for mont_mul).  A zero divisor raises *flag (field.rs:101-103) and gets 0;
 // the other elements of the batch are unaffected.
 // A workgroup inverts 256·T divisors with ONE field inversion: each lane multiplies up its T divisors (strided by 256, so
-// loads coalesce), the 256 lane products are scanned from both ends in LDS, lane 0 inverts the workgroup product, every
-// lane gets the inverse of its own product as inv_total · (product before it) · (product after it) and walks its T
-// divisors back.  3 multiplies per element (+1 for the quotient) + 18/T for the scans + 160/(256·T) for the inversion,
+// loads coalesce), the 256 lane products go up a product tree in LDS, lane 0 inverts the root, the way down the tree hands
+// every lane the inverse of its own product (inverse of the root · product of all other lanes), and the lane walks its T
+// divisors back.  3 multiplies per element (+1 for the quotient) + ~2/T for the tree + 160/(256·T) for the inversion,
 // where the per-element Fermat ladder took ~190.
 // Raw canonical values are read as Montgomery forms (of x/R): mont_mul then needs no conversion on the way in, and the
 // leftover power of R is taken out of the ONE inverted value per workgroup.
@@ -31,13 +31,12 @@ __global__ __launch_bounds__(256) void k_fp_binop(const fp* __restrict__ a, cons
 // (~21 us) while the other 255 wait, which is what a large call spends its time on; so from 2^22 elements up the work is
 // split (api.hip: dev_fp_op): MODE 1 writes only each chunk's product to ext[chunk]; those few thousand products are
 // inverted by one small MODE 0 launch; MODE 2 is MODE 0 with the chunk's inverted product read from ext[chunk] instead of
-// computed.  7.3 multiplies per element instead of 5.3, and no lane ever waits for an inversion.
+// computed.  One more pass of lane products and a tree, and no lane ever waits for an inversion.
 #define BINV_T 8
 template <int OP, int MODE>
 __global__ __launch_bounds__(256) void k_fp_batch_inv(const fp* __restrict__ a, const fp* __restrict__ b, fp* __restrict__ out, size_t n, uint32_t* __restrict__ flag,
                                                       fp* __restrict__ ext) {
     __shared__ fp s_pre[2][256], s_suf[2][256];
-    __shared__ fp s_inv;
     const uint32_t tid = threadIdx.x;
     const fp* __restrict__ div = (OP == FPOP_DIV) ? b : a;
     for (size_t base = (size_t)blockIdx.x * (256 * BINV_T); base < n; base += (size_t)gridDim.x * (256 * BINV_T)) {
@@ -70,33 +69,38 @@ __global__ __launch_bounds__(256) void k_fp_batch_inv(const fp* __restrict__ a, 
             __syncthreads();
             continue;
         }
-        // inclusive scans of the lane products from the front (s_pre) and from the back (s_suf), ping-pong buffers
-        s_pre[0][tid] = run;
-        s_suf[0][tid] = run;
+        // Product tree over the 256 lane products (heap layout: node i has children 2i, 2i+1, leaves at 256 + lane): up to the
+        // chunk's product at the root, then down again with out[child] = out[parent] · sibling, seeded with the inverse of the
+        // root — a leaf ends with inverse(root) · (product of all other lanes) = the inverse of its own lane product.  One
+        // thread per node, so a level of <= 64 nodes costs one wave one multiply: 21 wave-multiplies a chunk, against the 72 of
+        // a two-ended Hillis-Steele scan over all 256 lanes (which this kernel used first).
+        fp* const tr = &s_pre[0][0];                                      // 512 nodes each (s_pre and s_suf are 2 x 256)
+        fp* const dn = &s_suf[0][0];
+        tr[256 + tid] = run;
         __syncthreads();
-        int cur = 0;
 #pragma unroll 1
-        for (uint32_t off = 1; off < 256; off <<= 1) {
-            fp f = s_pre[cur][tid], g = s_suf[cur][tid];
-            if (tid >= off) f = mont_mul(s_pre[cur][tid - off], f);
-            if (tid + off < 256) g = mont_mul(g, s_suf[cur][tid + off]);
-            s_pre[cur ^ 1][tid] = f;
-            s_suf[cur ^ 1][tid] = g;
+        for (uint32_t size = 128; size; size >>= 1) {
+            if (tid < size) tr[size + tid] = mont_mul(tr[2 * (size + tid)], tr[2 * (size + tid) + 1]);
             __syncthreads();
-            cur ^= 1;
         }
-        if (MODE == 2) { if (tid == 0) s_inv = ext[chunk]; }
-        else if (tid == 0) {
-            fp t = mont_inv(s_pre[cur][255]);                             // never zero: zeros were replaced by one
-            t = fp_from_mont(t);                                          // R/x per element ...
-            if (OP == FPOP_INV) t = fp_from_mont(t);                      // ... or 1/x
-            s_inv = t;
+        if (tid == 0) {
+            fp t;
+            if (MODE == 2) t = ext[chunk];
+            else {
+                t = mont_inv(tr[1]);                                      // never zero: zeros were replaced by one
+                t = fp_from_mont(t);                                      // R/x per element ...
+                if (OP == FPOP_INV) t = fp_from_mont(t);                  // ... or 1/x
+            }
+            dn[1] = t;
         }
         __syncthreads();
-        fp inv = s_inv;
-        if (tid > 0) inv = mont_mul(inv, s_pre[cur][tid - 1]);
-        if (tid < 255) inv = mont_mul(inv, s_suf[cur][tid + 1]);
-        __syncthreads();                                                  // the scan buffers are reused by the next chunk
+#pragma unroll 1
+        for (uint32_t size = 2; size <= 256; size <<= 1) {               // `size` nodes on this level, one thread each
+            if (tid < size) dn[size + tid] = mont_mul(dn[(size + tid) >> 1], tr[(size + tid) ^ 1]);
+            __syncthreads();
+        }
+        fp inv = dn[256 + tid];
+        __syncthreads();                                                  // the tree buffers are reused by the next chunk
 #pragma unroll
         for (int j = BINV_T - 1; j >= 0; --j) {
             const size_t i = base + (size_t)j * 256 + tid;
