@@ -230,6 +230,11 @@ def main():
             calls[0] = 0
             dt_b = timed(batch_commit, max(5, args.steps), 2)
             del fresh, fresh_handles
+        # the front end of that batch: 128 polynomials of 2^12 coefficients -> 128 codewords of 2^14, one launch per NTT pass
+        d_bc = resident_codeword(Bb * (nb >> 2), 3500 + rank)
+        dt_l = timed(lambda: (_lib.check(_lib.lib.sh_dev_coset_lde_batch(H, d_bc.ptr, Bb, 12, 2, _u64p(scalar(sa.GENERATOR)), d_b.ptr)), ctx.sync()), 5, 2)
+        extra["lde_batch_128x2^12_to_2^14_ms"] = 1e3 * dt_l / 5
+        d_bc.free()
         extra["batch_128x2^14_elems_per_s"] = world * Bb * nb * max(5, args.steps) / dt_b
         extra["batch_128x2^14_ms"] = 1e3 * dt_b / max(5, args.steps)
         d_b.free()

@@ -101,6 +101,10 @@ int32_t sh_coset_lde(sh_ctx* ctx, const uint64_t* coeffs, uint32_t log_n, uint32
                      const uint64_t offset[2], uint64_t* out);
 int32_t sh_dev_coset_lde(sh_ctx* ctx, const uint64_t* d_coeffs, uint32_t log_n, uint32_t log_expansion,
                          const uint64_t offset[2], uint64_t* d_out);
+/* `batch` (<= 65535) polynomials of 2^log_n coefficients stored back to back -> their extensions back to back, one launch per NTT
+ * pass for all of them: the front end of a batch of commits (BASELINE.json C4: 1024 codewords of 2^14).  No reference counterpart. */
+int32_t sh_dev_coset_lde_batch(sh_ctx* ctx, const uint64_t* d_coeffs, size_t batch, uint32_t log_n, uint32_t log_expansion,
+                               const uint64_t offset[2], uint64_t* d_out);
 
 /* ---------------- polynomial layer ----------------
  * NO COUNTERPART IN THE REFERENCE CRATE (it has no polynomial type): these are the operations a STARK prover

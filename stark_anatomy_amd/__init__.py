@@ -19,7 +19,7 @@ from .context import Context, DeviceBuffer, array_to_ints, default_context, elem
 from .field import GENERATOR, ONE, PRIME, ZERO, FieldElement, FieldVector, generator, root_of_unity
 from .fri import Fri, fold, sample, sample_indices
 from .merkle import MerkleHash, MerkleTree, commit_elems, hash_leaves
-from .ntt import coset_lde, dev_coset_lde, dev_ntt, intt, ntt
+from .ntt import coset_lde, dev_coset_lde, dev_coset_lde_batch, dev_ntt, intt, ntt
 from .poly import coset_zerofier_div, poly_divmod_zerofier, poly_mul
 from .proof_stream import OutOfBoundsReadIndexError, ProofItem, ProofStream, ProofStreamError, SerializationError
 
@@ -27,6 +27,6 @@ __all__ = [
     "StarkHipError", "Context", "DeviceBuffer", "default_context", "elems_to_array", "array_to_ints",
     "PRIME", "GENERATOR", "ZERO", "ONE", "FieldElement", "FieldVector", "generator", "root_of_unity",
     "Fri", "fold", "sample", "MerkleHash", "MerkleTree", "commit_elems", "hash_leaves",
-    "ntt", "intt", "coset_lde", "dev_ntt", "dev_coset_lde", "poly_mul", "coset_zerofier_div", "poly_divmod_zerofier",
+    "ntt", "intt", "coset_lde", "dev_ntt", "dev_coset_lde", "dev_coset_lde_batch", "poly_mul", "coset_zerofier_div", "poly_divmod_zerofier",
     "ProofStream", "ProofItem", "ProofStreamError", "OutOfBoundsReadIndexError", "SerializationError",
 ]

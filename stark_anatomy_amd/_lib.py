@@ -89,6 +89,7 @@ _PROTOS = {
     "sh_poly_divmod_zerofier": (C.c_int32, [ctx_t, u64p, C.c_size_t, C.c_size_t, u64p, u64p, u64p]),
     "sh_dev_poly_divmod_zerofier": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_size_t, u64p, C.c_void_p, C.c_void_p]),
     "sh_dev_coset_lde": (C.c_int32, [ctx_t, C.c_void_p, C.c_uint32, C.c_uint32, u64p, C.c_void_p]),
+    "sh_dev_coset_lde_batch": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, u64p, C.c_void_p]),
     "sh_merkle_commit": (C.c_int32, [ctx_t, u8p, C.c_size_t, u8p]),
     "sh_dev_merkle_commit": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, u8p]),
     "sh_hash_leaves": (C.c_int32, [ctx_t, u64p, C.c_size_t, u8p]),

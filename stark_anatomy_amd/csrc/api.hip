@@ -316,28 +316,30 @@ int32_t sh_ntt(sh_ctx* c, uint64_t* data, uint32_t log_n, int32_t inverse) {
     HIPCHK(hipStreamSynchronize(c->stream));
     return SH_OK;
 }
-int32_t sh_dev_coset_lde(sh_ctx* c, const uint64_t* d_coeffs, uint32_t log_n, uint32_t log_expansion, const uint64_t offset[2], uint64_t* d_out) {
+int32_t sh_dev_coset_lde_batch(sh_ctx* c, const uint64_t* d_coeffs, size_t batch, uint32_t log_n, uint32_t log_expansion, const uint64_t offset[2], uint64_t* d_out) {
     CTXCHK(c);
+    if (!batch) return SH_OK;
     if (!d_coeffs || !offset || !d_out) return sh_fail(SH_EINVAL, "sh_dev_coset_lde: null pointer");
     if (log_n + log_expansion > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "sh_dev_coset_lde: log_n + log_expansion > %d", SH_MAX_LOG_N);
+    const uint32_t log_N = log_n + log_expansion;
+    if (batch > 65535 || batch > ((size_t)1 << (SH_MAX_LOG_N + 2 - log_N))) return sh_failf(SH_EINVAL, "sh_dev_coset_lde_batch: batch %zu x 2^%u exceeds 65535 polynomials or 2^%d elements", batch, log_N, SH_MAX_LOG_N + 2);
     const fp off = fp_load_host(offset);
     if (!fp_is_canonical(off)) return sh_fail(SH_EINVAL, "sh_dev_coset_lde: non-canonical offset");
     const size_t n = (size_t)1 << log_n, N = n << log_expansion;
-    const uint32_t log_N = log_n + log_expansion;
     NttPlan plan;
     ntt_make_plan(log_N, &plan);
     NttLdeShape sh;
     static const bool no_fuse = getenv("STARK_NO_LDE_FUSE") != nullptr;
     if (no_fuse || d_coeffs == d_out || !ntt_lde_fusable(plan, log_expansion, &sh)) {
-        HIPCHK(launch_coset_scale_pad((const fp*)d_coeffs, n, off, (fp*)d_out, N, c->stream));
-        return dev_ntt(c, (fp*)d_out, log_N, false);
+        HIPCHK(launch_coset_scale_pad((const fp*)d_coeffs, n, off, (fp*)d_out, N, c->stream, batch));
+        return dev_ntt(c, (fp*)d_out, log_N, false, batch);
     }
     // Fused form: no zero-padded, pre-scaled copy of the coefficients is ever written — the first NTT pass reads the n
     // coefficients, scales them by offset^j on the way into LDS and never touches the padding (one HBM pass less).
     const fp* tw;
     SHCHK(get_twiddles(c, log_N, false, &tw));
     void *scratch, *tab;
-    SHCHK(ensure_scratch(c, SCR_WORK, N * sizeof(fp), &scratch));
+    SHCHK(ensure_scratch(c, SCR_WORK, batch * N * sizeof(fp), &scratch));
     SHCHK(ensure_scratch(c, SCR_LDE_TAB, (sh.rows + sh.chunks + sh.cols) * sizeof(fp), &tab));
     fp* pow_row = (fp*)tab, *pow_chunk = pow_row + sh.rows, *pow_col = pow_chunk + sh.chunks;
     auto pow2k = [&](uint32_t k) { fp b = fp_to_mont(off); for (uint32_t i = 0; i < k; ++i) b = mont_mul(b, b); return b; };   // offset^(2^k), Montgomery form
@@ -347,8 +349,11 @@ int32_t sh_dev_coset_lde(sh_ctx* c, const uint64_t* d_coeffs, uint32_t log_n, ui
     const NttLdeFuse fuse{(const fp*)d_coeffs, log_expansion, pow_row, pow_chunk, pow_col};
     NttPassTables ptab;
     SHCHK(get_pass_tables(c, plan, false, tw, &ptab));
-    HIPCHK(launch_ntt(plan, (fp*)d_out, (fp*)scratch, tw, fp_mont_one(), false, 1, c->stream, &fuse, &ptab));
+    HIPCHK(launch_ntt(plan, (fp*)d_out, (fp*)scratch, tw, fp_mont_one(), false, batch, c->stream, &fuse, &ptab));
     return SH_OK;
+}
+int32_t sh_dev_coset_lde(sh_ctx* c, const uint64_t* d_coeffs, uint32_t log_n, uint32_t log_expansion, const uint64_t offset[2], uint64_t* d_out) {
+    return sh_dev_coset_lde_batch(c, d_coeffs, 1, log_n, log_expansion, offset, d_out);
 }
 int32_t sh_coset_lde(sh_ctx* c, const uint64_t* coeffs, uint32_t log_n, uint32_t log_expansion, const uint64_t offset[2], uint64_t* out) {
     CTXCHK(c);

@@ -78,7 +78,7 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
 hipError_t launch_scale_powers(fp* data, size_t count, fp start_mont, fp base, hipStream_t s);
 hipError_t launch_twiddle_scale(fp* data, size_t rows, uint32_t log_cols, uint64_t row0, uint64_t col0, const fp* tw, uint32_t log_n, hipStream_t s);
 // out[j] = j < n ? coeffs[j]·offset^j : 0   for j < N  (coset pre-scale + zero pad, G7)
-hipError_t launch_coset_scale_pad(const fp* coeffs, size_t n, fp offset, fp* out, size_t N, hipStream_t s);
+hipError_t launch_coset_scale_pad(const fp* coeffs, size_t n, fp offset, fp* out, size_t N, hipStream_t s, size_t batch = 1);   // batch <= 65535 polynomials back to back
 
 // ---- hash_kernels.hip ----
 // out[i] = Blake2b512(le16(elems[i]))

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams p) {
     const uint32_t tid = threadIdx.x;
     const size_t tile = blockIdx.x & ((1u << p.log_tiles) - 1);
     const size_t xform = (size_t)(blockIdx.x >> p.log_tiles) << p.log_n;   // batched: transforms are contiguous
-    const fp* __restrict__ in = p.in + xform;
+    const fp* __restrict__ in = p.in + (p.fuse_log_e ? xform >> p.fuse_log_e : xform);   // fused LDE: the inputs are the short coefficient vectors
     fp* __restrict__ out = p.out + xform;
 
     for (uint32_t e = tid; e < (R >> 1); e += blockDim.x) twr[e] = ntt_load_tw(p.tw, p.log_n, (size_t)e << (p.log_n - p.log_r));
@@ -289,7 +289,6 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
             p.in = data;                                               // non-final passes work in place on `data` ...
             p.out = (pi + 2 == P) ? scratch : data;                    // ... except the last one, which lands in scratch
             if (pi == 0 && fuse) {                                     // coset LDE: the first pass reads the coefficients themselves
-                if (batch != 1) return hipErrorInvalidValue;
                 p.in = fuse->coeffs; p.fuse_log_e = fuse->log_expansion;
                 p.pow_row = fuse->pow_row; p.pow_chunk = fuse->pow_chunk; p.pow_col = fuse->pow_col;
             }
@@ -320,6 +319,8 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
 __global__ __launch_bounds__(256) void k_coset_scale_pad(const fp* __restrict__ coeffs, size_t n, fp offset, fp* __restrict__ out, size_t N) {
     const size_t j0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * SCALE_PER_THREAD;
     if (j0 >= N) return;
+    coeffs += (size_t)blockIdx.y * n;                                    // blockIdx.y: index in a batch of polynomials stored back to back
+    out += (size_t)blockIdx.y * N;
     if (j0 >= n) {
 #pragma unroll
         for (int q = 0; q < SCALE_PER_THREAD; ++q) if (j0 + q < N) out[j0 + q] = fp_zero();
@@ -337,9 +338,11 @@ __global__ __launch_bounds__(256) void k_coset_scale_pad(const fp* __restrict__ 
     }
 }
 
-hipError_t launch_coset_scale_pad(const fp* coeffs, size_t n, fp offset, fp* out, size_t N, hipStream_t s) {
+hipError_t launch_coset_scale_pad(const fp* coeffs, size_t n, fp offset, fp* out, size_t N, hipStream_t s, size_t batch) {
+    if (!batch) return hipSuccess;
+    if (batch > 65535) return hipErrorInvalidValue;
     const size_t threads = (N + SCALE_PER_THREAD - 1) / SCALE_PER_THREAD;
-    hipLaunchKernelGGL(k_coset_scale_pad, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, coeffs, n, offset, out, N);
+    hipLaunchKernelGGL(k_coset_scale_pad, dim3((unsigned)((threads + 255) / 256), (unsigned)batch), dim3(256), 0, s, coeffs, n, offset, out, N);
     return hipGetLastError();
 }
 

@@ -41,3 +41,8 @@ def dev_ntt(ctx, d_data, log_n, inverse=False):
 
 def dev_coset_lde(ctx, d_coeffs, log_n, log_expansion, offset, d_out):
     check(lib.sh_dev_coset_lde(ctx.handle, device_ptr(d_coeffs), log_n, log_expansion, _u64p(scalar(offset)), device_ptr(d_out)))
+
+
+def dev_coset_lde_batch(ctx, d_coeffs, batch, log_n, log_expansion, offset, d_out):
+    """`batch` polynomials of 2^log_n coefficients back to back -> their coset extensions back to back (sh_dev_coset_lde_batch)"""
+    check(lib.sh_dev_coset_lde_batch(ctx.handle, device_ptr(d_coeffs), batch, log_n, log_expansion, _u64p(scalar(offset)), device_ptr(d_out)))

@@ -248,6 +248,25 @@ def test_lde_golden_and_oracle(ctx, golden):
         assert (sa.coset_lde(c, le, off, ctx=ctx) == co.coset_lde(c, le, off)).all()
 
 
+@pytest.mark.parametrize("batch,log_n,log_e", [(5, 3, 2), (3, 10, 2), (128, 12, 2), (7, 12, 3), (2, 16, 0), (4, 9, 1), (1, 18, 2)])
+def test_lde_batch_equals_single_and_oracle(ctx, batch, log_n, log_e):
+    """sh_dev_coset_lde_batch: `batch` polynomials back to back through one launch per pass == one sh_dev_coset_lde each
+    == the oracle (first and last polynomial; all of them when small)."""
+    n, N = 1 << log_n, 1 << (log_n + log_e)
+    c = co.splitmix_elems(500 + batch + log_n, batch * n)
+    d_c = ctx.alloc(batch * n * 16).upload(c)
+    d_o = ctx.alloc(batch * N * 16)
+    sa.dev_coset_lde_batch(ctx, d_c, batch, log_n, log_e, G, d_o)
+    got = d_o.download(np.uint64, (batch, N, 2))
+    d_1 = ctx.alloc(N * 16)
+    for b in range(batch):
+        sa.dev_coset_lde(ctx, d_c.ptr + b * n * 16, log_n, log_e, G, d_1)
+        assert (d_1.download(np.uint64, (N, 2)) == got[b]).all(), b
+    for b in sorted({0, batch - 1} | (set(range(batch)) if log_n <= 10 else set())):
+        assert (got[b] == co.coset_lde(np.ascontiguousarray(c[b * n:(b + 1) * n]), log_e, G)).all(), b
+    d_c.free(); d_o.free(); d_1.free()
+
+
 def test_c2_ntt_lde_merkle(ctx, golden):
     """BASELINE config 2: single 2^16 NTT + coset LDE + Merkle commit, bit-exact vs CPU."""
     e = golden("c2_lde_merkle.json")
