@@ -37,6 +37,10 @@
 #define LSHR_I(i) "v_lshrrev_b32 %" #i ", 7, %" #i "\n"
 // sub-dword addressing: a xor that reads word 1 of both sources and writes word 0 of the destination, the rest of it kept (the
 // xor and the rotate by 16 of Blake2b's G in one instruction per 16-bit word) or zeroed
+// 24-bit multiplies: would a field multiply on 24-bit limbs issue faster than 20 v_mad_u64_u32?
+#define MUL24_I(i) "v_mul_u32_u24 %" #i ", %" #i ", %8\n"
+#define MULHI24_I(i) "v_mul_hi_u32_u24 %" #i ", %" #i ", %8\n"
+#define MAD24_I(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %8\n"
 #define SDWAP_I(i) "v_xor_b32_sdwa %" #i ", %" #i ", %8 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1\n"
 #define SDWAZ_I(i) "v_xor_b32_sdwa %" #i ", %" #i ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n"
 #define SDWAB_I(i) "v_xor_b32_sdwa %" #i ", %" #i ", %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n"
@@ -68,6 +72,9 @@ __global__ __launch_bounds__(256) void k32(uint32_t* out, int iters, uint32_t se
         if (KIND == 20) asm volatile(BLOCK(SDWAP_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
         if (KIND == 21) asm volatile(BLOCK(SDWAZ_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
         if (KIND == 22) asm volatile(BLOCK(SDWAB_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 23) asm volatile(BLOCK(MUL24_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 24) asm volatile(BLOCK(MULHI24_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        if (KIND == 25) asm volatile(BLOCK(MAD24_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
         if (KIND == 8) asm volatile(BLOCK(ADDCOP_I) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
@@ -143,7 +150,8 @@ int main() {
     CHK(hipMalloc(&buf, (size_t)256 * 8 * 4 * 256 * 8));
     const char* n32[] = {"v_xor_b32", "v_add_u32", "v_alignbit_b32", "v_alignbyte_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_add3_u32", "v_xad_u32", "add_co+addc (x2 instr)",
                          "v_xor_b32_e64 (VOP3 enc)", "v_add_u32_e64 (VOP3 enc)", "v_fma_f32 (VOP3)", "v_perm_b32", "v_bfi_b32", "v_or3_b32", "v_lshl_or_b32", "v_fmac_f32 (VOP2)", "v_lshrrev_b32 (VOP2)", "v_pack_b32_f16 op_sel", "v_cndmask_b32 (VOP2+vcc)",
-                         "v_xor_b32_sdwa word->word keep", "v_xor_b32_sdwa word->dword", "v_xor_b32_sdwa byte->byte keep"};
+                         "v_xor_b32_sdwa word->word keep", "v_xor_b32_sdwa word->dword", "v_xor_b32_sdwa byte->byte keep",
+                         "v_mul_u32_u24", "v_mul_hi_u32_u24", "v_mad_u32_u24"};
     const char* n64[] = {"v_lshl_add_u64", "v_mad_u64_u32", "v_lshrrev_b64", "v_lshlrev_b64", "v_mov_b64"};
     for (int wps = 4; wps <= 8; wps *= 2) {                // waves per SIMD
         const int blocks = 256 * wps;                      // 256 CUs x (wps*4 waves = wps blocks of 256 threads)
@@ -153,7 +161,7 @@ int main() {
 #define RUN32(K) ms = time_ms([&] { hipLaunchKernelGGL(k32<K>, dim3(blocks), dim3(256), 0, 0, (uint32_t*)buf, iters, 7u); }); \
         printf("%-26s %8.3f ms  %8.2f T lane-ops/s  %5.2f cycles/instr/SIMD @2.4GHz\n", n32[K], ms, lane_ops / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)wps * iters * 64));
         RUN32(0) RUN32(1) RUN32(2) RUN32(3) RUN32(4) RUN32(5) RUN32(6) RUN32(7) RUN32(8)
-        RUN32(9) RUN32(10) RUN32(11) RUN32(12) RUN32(13) RUN32(14) RUN32(15) RUN32(16) RUN32(17) RUN32(18) RUN32(19) RUN32(20) RUN32(21) RUN32(22)
+        RUN32(9) RUN32(10) RUN32(11) RUN32(12) RUN32(13) RUN32(14) RUN32(15) RUN32(16) RUN32(17) RUN32(18) RUN32(19) RUN32(20) RUN32(21) RUN32(22) RUN32(23) RUN32(24) RUN32(25)
 #define RUN64(K) ms = time_ms([&] { hipLaunchKernelGGL(k64<K>, dim3(blocks), dim3(256), 0, 0, (uint64_t*)buf, iters, 7u); }); \
         printf("%-26s %8.3f ms  %8.2f T lane-ops/s  %5.2f cycles/instr/SIMD @2.4GHz\n", n64[K], ms, lane_ops / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)wps * iters * 64));
         RUN64(0) RUN64(1) RUN64(2) RUN64(3) RUN64(4)
