@@ -19,15 +19,14 @@ int32_t sh_dev_poly_mul(sh_ctx* c, const uint64_t* d_a, size_t na, const uint64_
     if (m < na || m > ((size_t)1 << SH_MAX_LOG_N)) return sh_failf(SH_EINVAL, "sh_poly_mul: product has more than 2^%d coefficients", SH_MAX_LOG_N);
     const uint32_t lg = ilog2(m);
     const size_t n = (size_t)1 << lg;
-    void *A, *B;
-    SHCHK(ensure_scratch(c, SCR_POLY_A, n * sizeof(fp), &A));
-    SHCHK(ensure_scratch(c, SCR_POLY_B, n * sizeof(fp), &B));
+    void *A, *B;                                              // both zero-padded operands back to back: their two forward transforms are one batch (one launch per pass)
+    SHCHK(ensure_scratch(c, SCR_POLY_A, 2 * n * sizeof(fp), &A));
+    B = (fp*)A + n;
     HIPCHK(hipMemcpyAsync(A, d_a, na * sizeof(fp), hipMemcpyDeviceToDevice, c->stream));
     if (n > na) HIPCHK(hipMemsetAsync((fp*)A + na, 0, (n - na) * sizeof(fp), c->stream));
     HIPCHK(hipMemcpyAsync(B, d_b, nb * sizeof(fp), hipMemcpyDeviceToDevice, c->stream));
     if (n > nb) HIPCHK(hipMemsetAsync((fp*)B + nb, 0, (n - nb) * sizeof(fp), c->stream));
-    SHCHK(dev_ntt(c, (fp*)A, lg, false));
-    SHCHK(dev_ntt(c, (fp*)B, lg, false));
+    SHCHK(dev_ntt(c, (fp*)A, lg, false, 2));
     HIPCHK(launch_fp_binop(FPOP_MUL, (const fp*)A, (const fp*)B, (fp*)A, n, c->d_flag, c->stream));
     SHCHK(dev_ntt(c, (fp*)A, lg, true));
     HIPCHK(hipMemcpyAsync(d_out, A, m * sizeof(fp), hipMemcpyDeviceToDevice, c->stream));
