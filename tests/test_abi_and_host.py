@@ -6,6 +6,7 @@ CPU-side checks of the product library (no GPU needed, no compute kernels run):
     roots of unity, scalar field ops) match the reference's KATs, the golden vectors and the oracle.
 """
 import ctypes as C
+import hashlib
 import json
 import os
 import random
@@ -193,6 +194,69 @@ def test_deserialize_bulk_items_raw_or_verbatim():
             assert odd == b'[{"Path":[{"inner":[007]}]}]'              # a leading zero is not JSON: rejected by the general scanner
             continue
         assert again == odd
+
+
+def test_deserialize_random_json_round_trips():
+    """Random JSON streams, tokens separated by random white space: deserialize -> serialize must give exactly the tokens
+    joined without white space (proof_stream.rs:42-49 then :38-40 on canonical text) — through the general scanner, its
+    integer-run shortcut and the raw take-over of Path / Leaves / Codeword items alike."""
+    rnd = random.Random(2024)
+
+    def num():
+        k = rnd.randrange(8)
+        if k == 0: return "0"
+        if k == 1: return str(rnd.randrange(256))
+        if k == 2: return str(rnd.randrange(1 << 128))
+        if k == 3: return "-" + str(rnd.randrange(1, 10**6))
+        if k == 4: return str(rnd.randrange(1, 10**4)) + "." + str(rnd.randrange(10)) + str(rnd.randrange(1, 10))
+        if k == 5: return str(rnd.randrange(1, 99)) + "e" + rnd.choice(["", "+", "-"]) + str(rnd.randrange(1, 30))
+        if k == 6: return str(rnd.randrange(1 << 140))
+        return str(rnd.randrange(10**rnd.randrange(1, 12)))
+
+    def value(depth):
+        k = rnd.randrange(10 if depth < 4 else 6)
+        if k < 3: return [num()]
+        if k == 3: return [rnd.choice(["true", "false", "null"])]
+        if k < 6: return ['"' + "".join(rnd.choice(["a", "b", " ", "x", "_", ":", ",", "[", "]", "{", "}", "\\n", '\\"', "\\\\", "\\u0041"]) for _ in range(rnd.randrange(6))) + '"']
+        if k < 8:
+            out = ["["]
+            for i in range(rnd.randrange(0, 12)):
+                if i: out.append(",")
+                out += [num()] if rnd.random() < 0.7 else value(depth + 1)
+            return out + ["]"]
+        out = ["{"]
+        for i in range(rnd.randrange(0, 4)):
+            if i: out.append(",")
+            out += ['"k%d"' % i, ":"] + value(depth + 1)
+        return out + ["}"]
+
+    def typed():
+        k = rnd.randrange(4)
+        if k == 0:
+            hs = [[str(rnd.randrange(256 if rnd.random() < 0.97 else 300)) for _ in range(64 if rnd.random() < 0.95 else 63)] for _ in range(rnd.randrange(0, 4))]
+            out = ["{", '"Path"', ":", "["]
+            for i, h in enumerate(hs):
+                if i: out.append(",")
+                out += ["{", '"inner"', ":", "["] + [t for j, v in enumerate(h) for t in (([","] if j else []) + [v])] + ["]", "}"]
+            return out + ["]", "}"]
+        tag = '"Leaves"' if k == 1 else '"Codeword"' if k == 2 else '"MerkleRoot"'
+        if k == 3:
+            return ["{", tag, ":", "{", '"inner"', ":", "["] + [t for j in range(64) for t in (([","] if j else []) + [str(rnd.randrange(256))])] + ["]", "}", "}"]
+        vals = [str(rnd.randrange(1 << rnd.choice([7, 64, 127, 128, 130]))) for _ in range(rnd.randrange(0, 9))]
+        return ["{", tag, ":", "["] + [t for j, v in enumerate(vals) for t in (([","] if j else []) + [v])] + ["]", "}"]
+
+    for trial in range(300):
+        toks = ["["]
+        for i in range(rnd.randrange(0, 6)):
+            if i: toks.append(",")
+            toks += typed() if rnd.random() < 0.5 else value(0)
+        toks.append("]")
+        compact = "".join(toks).encode()
+        ws = rnd.choice([0.0, 0.0, 0.05, 0.5])
+        spaced = "".join(t + ("".join(rnd.choice(" \n\t\r") for _ in range(rnd.randrange(1, 3))) if rnd.random() < ws else "") for t in toks).encode()
+        ps = sa.ProofStream.deserialize(spaced)
+        assert ps.serialize() == compact, (trial, spaced[:200])
+        assert sa.ProofStream.deserialize(compact).prover_fiat_shamir() == hashlib.sha256(compact).digest()
 
 
 def test_merkle_verify_host_matches_oracle():
