@@ -102,7 +102,8 @@ int32_t sh_coset_lde(sh_ctx* ctx, const uint64_t* coeffs, uint32_t log_n, uint32
 int32_t sh_dev_coset_lde(sh_ctx* ctx, const uint64_t* d_coeffs, uint32_t log_n, uint32_t log_expansion,
                          const uint64_t offset[2], uint64_t* d_out);
 /* `batch` (<= 65535) polynomials of 2^log_n coefficients stored back to back -> their extensions back to back, one launch per NTT
- * pass for all of them: the front end of a batch of commits (BASELINE.json C4: 1024 codewords of 2^14).  No reference counterpart. */
+ * pass for all of them: the front end of a batch of commits (BASELINE.json C4: 1024 codewords of 2^14).  No reference counterpart.
+ * Aliasing: d_coeffs == d_out (in place) is allowed for batch == 1 only; any other overlap of the two ranges is SH_EINVAL. */
 int32_t sh_dev_coset_lde_batch(sh_ctx* ctx, const uint64_t* d_coeffs, size_t batch, uint32_t log_n, uint32_t log_expansion,
                                const uint64_t offset[2], uint64_t* d_out);
 
@@ -142,7 +143,8 @@ int32_t sh_dev_merkle_commit_elems(sh_ctx* ctx, const uint64_t* d_elems, size_t 
  * This is the dominant kernel of the commit; also the building block for batches of small commits. */
 int32_t sh_dev_merkle_subtrees(sh_ctx* ctx, const uint64_t* d_elems, size_t n_out, uint32_t K, uint8_t* d_out);
 /* Allocation-free variant of sh_dev_merkle_commit_elems.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
- * cannot allocate device memory — code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * cannot allocate device memory — tight serving loops, harnesses that forbid hipMalloc.  It allocates nothing, but it still waits for the root on
+ * the host (mailbox poll, or a copy and a stream synchronise), so it cannot run under stream capture.
  * Same kernels and the same root as sh_dev_merkle_commit_elems, but the digest buffers live in a fixed 8 MiB + 33 KiB
  * __device__ array of the library (one copy per GPU, held until the process ends) instead of the context's growable
  * scratch; it calls no hipMalloc / hipFree.  L must be a power of two <= 2^SH_NOALLOC_MAX_LOG_L (else SH_EINVAL).
@@ -283,7 +285,10 @@ int32_t sh_merkle_verify(const uint8_t root[64], const uint8_t leaf[64], const u
 int32_t sh_sample_field(const uint8_t digest[32], uint64_t out[2]);                     /* G3 */
 int32_t sh_root_of_unity(uint32_t log_n, uint64_t out[2]);                              /* G1 */
 int32_t sh_generator(uint64_t out[2]);                                                  /* G1 */
-/* scalar field ops: op 0 add, 1 sub, 2 mul, 3 div, 4 pow (true modular) — FieldElement operators for single values */
+/* scalar field ops: op 0 add, 1 sub, 2 mul, 3 div, 4 pow — FieldElement operators for single values (field.rs:57-114).
+ * Op 4 is TRUE modular exponentiation a^b mod p for any exponent.  It is deliberately not field.rs:37-46, which raises the
+ * value as a plain 320-bit integer (I320::pow, base.rs:30-42, wrapping mod 2^320) and reduces once at the end: the two agree
+ * while a^b < 2^319 (the crate's only test, 2^160, field.rs:140-151, passes here) and differ beyond. */
 int32_t sh_fp_scalar(int32_t op, const uint64_t a[2], const uint64_t b[2], uint64_t out[2]);
 
 #ifdef __cplusplus

@@ -127,6 +127,7 @@ int32_t sh_ctx_destroy(sh_ctx* c) {
     if (c->sub) { (void)sh_ctx_destroy(c->sub); c->sub = nullptr; (void)hipSetDevice(c->device); }
     if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
     delete c->pool;
+    delete c->enqueuer;
     if (getenv("STARK_HIP_DEBUG")) fprintf(stderr, "[stark_hip] ctx %p: mailbox roots %u, fallbacks %llu\n", (void*)c, c->mail_seq, (unsigned long long)c->mail_fallbacks);
     for (auto& kv : c->tw_cache) (void)hipFree(kv.second);
     for (auto& kv : c->ptw_cache) (void)hipFree(kv.second);
@@ -326,6 +327,13 @@ int32_t sh_dev_coset_lde_batch(sh_ctx* c, const uint64_t* d_coeffs, size_t batch
     const fp off = fp_load_host(offset);
     if (!fp_is_canonical(off)) return sh_fail(SH_EINVAL, "sh_dev_coset_lde: non-canonical offset");
     const size_t n = (size_t)1 << log_n, N = n << log_expansion;
+    // Aliasing: in place (d_coeffs == d_out) is defined for ONE polynomial only; with batch > 1 polynomial 0's padded output
+    // would overwrite coefficients not yet read.  Any other overlap of the two ranges is an error too.
+    {
+        const uintptr_t ci = (uintptr_t)d_coeffs, ce = ci + batch * n * sizeof(fp), oi = (uintptr_t)d_out, oe = oi + batch * N * sizeof(fp);
+        const bool overlap = ci < oe && oi < ce;
+        if (overlap && !(batch == 1 && ci == oi)) return sh_fail(SH_EINVAL, "sh_dev_coset_lde_batch: input and output overlap (in place is defined for batch == 1 with d_coeffs == d_out only)");
+    }
     NttPlan plan;
     ntt_make_plan(log_N, &plan);
     NttLdeShape sh;

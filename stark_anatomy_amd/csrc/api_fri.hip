@@ -45,11 +45,13 @@ static int32_t ensure_chain(sh_ctx* c, size_t bytes) {
 // Releases the GPU on every exit path once kernels that wait for the host are in flight: publishes "abort" in every c0
 // record not yet published and drains the stream.
 struct ChainGuard {
-    sh_ctx* c; const ChainLayout* lay; uint32_t gen; size_t next_c0 = 0, waits = 0; bool armed = false;   // waits: c0 records 0..waits-1 have a kernel waiting
+    sh_ctx* c; const ChainLayout* lay; uint32_t gen; size_t next_c0 = 0, waits = 0; bool armed = false;   // waits: c0 records 0..waits-1 may have a kernel waiting
+    ChainEnqueuer* helper = nullptr;               // a posted job refers to the caller's frame: it must have returned before the frame goes
     ~ChainGuard() {
         if (!armed) return;
         for (size_t r = next_c0; r < waits; ++r)
             __atomic_store_n(reinterpret_cast<uint32_t*>(c->h_chain + lay->c0_seq(r)), gen | 0x80000000u, __ATOMIC_RELEASE);
+        if (helper) (void)helper->wait(nullptr);
         (void)hipStreamSynchronize(c->stream);
     }
 };
@@ -58,8 +60,8 @@ struct ChainGuard {
 // that itself waits for GPU work queued behind that spinning kernel (seen with two contexts in two threads).  So: poll the
 // record, the abort word that a wait kernel raises when its bounded spin runs out, and a wall clock.
 // Returns SH_OK, WAIT_RETRY (a wait kernel gave up: the caller re-enqueues from this round) or an error.
-static const int32_t WAIT_RETRY = 1;
-static int32_t wait_seq(sh_ctx* c, const uint32_t* flag, uint32_t gen, uint32_t round, double deadline_s) {
+static const int32_t WAIT_RETRY = 1, WAIT_ENQUEUE_FAILED = 2;
+static int32_t wait_seq(sh_ctx* c, const uint32_t* flag, uint32_t gen, uint32_t round, double deadline_s, const ChainEnqueuer* helper) {
     const volatile uint32_t* hd = reinterpret_cast<volatile uint32_t*>(c->h_chain);
     const auto t0 = std::chrono::steady_clock::now();
     uint64_t spins = 0;
@@ -67,6 +69,7 @@ static int32_t wait_seq(sh_ctx* c, const uint32_t* flag, uint32_t gen, uint32_t 
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == gen) return SH_OK;
         if ((++spins & 0xff) == 0) {
             if (hd[0]) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == gen ? SH_OK : WAIT_RETRY;
+            if (helper && helper->failed()) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == gen ? SH_OK : WAIT_ENQUEUE_FAILED;
             if ((spins & 0x3ff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadline_s) {
                 const hipError_t e = hipStreamQuery(c->stream);
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == gen) return SH_OK;
@@ -243,15 +246,35 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
     uint32_t* d_abort = c->d_flag + 32;
     uint32_t* h_abort = reinterpret_cast<uint32_t*>(c->h_chain);
     uint32_t* hd_abort = reinterpret_cast<uint32_t*>(c->d_chain);
-    for (int i = 0; i < 8; ++i) h_abort[i] = 0;
+    for (int i = 0; i < 16; ++i) h_abort[i] = 0;
+    // The layout depends on (B, R): a sequence word of this commit may lie where an earlier commit of another shape left a
+    // root, a fold constant or a staged codeword element — bytes that can equal `gen`.  The stream is drained (every commit
+    // ends with a synchronise), so nothing reads these words now: lower them all.
+    for (uint32_t r = 0; r < R; ++r) {
+        *reinterpret_cast<volatile uint32_t*>(c->h_chain + lay.root_seq(r)) = 0;
+        *reinterpret_cast<volatile uint32_t*>(c->h_chain + lay.c0_seq(r)) = 0;
+    }
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
     HIPCHK(hipMemsetAsync(d_abort, 0, 4, c->stream));
+    const bool dbg = getenv("STARK_HIP_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    // debug runs pair the device's 100 MHz clock with the host's once per commit (a tiny kernel stamps pinned memory, the host
+    // polls for it: good to a few us), so that a wait kernel's post-mortem stamps can be laid beside the host's own.
+    double cal_host_us = 0; uint64_t cal_ticks = 0;
+    if (dbg) {
+        volatile uint64_t* h_clk = reinterpret_cast<volatile uint64_t*>(h_abort + 12);
+        HIPCHK(launch_clock_probe(reinterpret_cast<uint64_t*>(hd_abort + 12), c->stream));
+        const double t_give_up = now() + 1e6;
+        while (!(cal_ticks = *h_clk) && now() < t_give_up) __builtin_ia32_pause();
+        cal_host_us = now();
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *h_clk = 0;
+    }
+    const double t_start = now();
 
-    // ---- enqueue rounds one ahead of the chain: round r+1's kernels (which start by waiting for challenge r) are on the
-    // stream before root r is picked up, and round r+2 is enqueued while the GPU works on round r+1.
-    // Round r >= 1 reads codeword r-1 (length N >> (r-1)) and writes codeword r; both are functions of r alone, so that a
-    // round can be enqueued a second time after its wait kernel gave up.
-    ChainGuard guard{c, &lay, gen};
-    guard.armed = true;
+    // ---- the kernels of ALL rounds are enqueued before the chain is served; round r+1's kernels start by waiting for
+    // challenge r.  Round r >= 1 reads codeword r-1 (length N >> (r-1)) and writes codeword r; both are functions of r alone,
+    // so that a round can be enqueued a second time after its wait kernel gave up.
     auto cw_of = [&](uint32_t r) -> fp* {          // codeword r, r >= 1: arena offset N - N/2^(r-1), or the ping-pong buffers
         return keep ? (fp*)arena + (N - (N >> (r - 1))) : (fp*)(((r - 1) & 1) ? bufY : bufX);
     };
@@ -294,7 +317,6 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
             const size_t L = N >> (r - 1), half = L / 2;
             const fp* in = r == 1 ? d_cws : cw_of(r - 1);
             fp* next = cw_of(r);
-            if (guard.waits < r) guard.waits = r;
             if (sh.small) SHCHK(small_round(true, in, next, ilog2(half)));
             else {
                 HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)),
@@ -309,42 +331,90 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
         if (enq == R && stage_last) HIPCHK(launch_copy_to_host(R > 1 ? cw_of(R - 1) : d_cws, reinterpret_cast<fp*>(c->d_chain + lay.off_last), B * L_last, c->stream));
         return SH_OK;
     };
-    SHCHK(enqueue_round());
-    if (R > 1) SHCHK(enqueue_round());
+    // Who makes the launches.  While a wait kernel spins on the GPU for a challenge, the thread that will produce that challenge
+    // must not be inside the HIP runtime: a launch can block behind another host thread's hipFree / context teardown, which waits
+    // for the device to go idle, i.e. for that very kernel — a cycle that only the kernel's bounded spin breaks (measured: the
+    // "stale" sequence words of round 2 were records the blocked host thread had not yet written).  So the
+    // caller enqueues round 0 (no wait in it) and the context's enqueue thread, which nothing on the GPU waits for, the rest;
+    // the caller then only reads and writes pinned memory.  STARK_HIP_CHAIN_INLINE_ENQUEUE=1 keeps round 2's scheme (the
+    // caller enqueues one round ahead between two challenges) for A/B runs.
+    static const bool inline_enq = getenv("STARK_HIP_CHAIN_INLINE_ENQUEUE") != nullptr;
+    ChainEnqueuer* helper = nullptr;
+    if (R >= 2 && !inline_enq) {
+        if (!c->enqueuer) { try { c->enqueuer = new ChainEnqueuer(c->device); } catch (const std::system_error&) { c->enqueuer = nullptr; } }
+        helper = c->enqueuer;                      // no thread to be had: the caller enqueues as in round 2
+    }
+    std::atomic<int> gate{0};                      // 0: round 0 not enqueued yet, 1: go, 2: round 0 failed
+    auto enqueue_rest = [&]() -> int32_t { while (enq < R) SHCHK(enqueue_round()); return SH_OK; };
+    std::string helper_msg;
+    ChainGuard guard{c, &lay, gen};                // declared after everything a posted job refers to
+    guard.waits = R - 1;
+    guard.helper = helper;
+    guard.armed = true;
+    if (helper) {
+        helper->post([&]() -> int32_t {            // woken now, so that it is awake by the time round 0 is on the stream
+            int g;
+            uint32_t spins = 0;
+            while ((g = gate.load(std::memory_order_acquire)) == 0) { if (++spins > 20000) std::this_thread::yield(); else __builtin_ia32_pause(); }
+            return g == 1 ? enqueue_rest() : SH_OK;
+        });
+        const int32_t rc0 = enqueue_round();
+        gate.store(rc0 == SH_OK ? 1 : 2, std::memory_order_release);
+        if (rc0 != SH_OK) return rc0;
+    } else {
+        SHCHK(enqueue_round());
+        if (R > 1) SHCHK(enqueue_round());
+    }
 
-    // ---- serve the chain: root_r -> transcript -> challenge_r -> fold constants
+    // ---- serve the chain: root_r -> transcript -> challenge_r -> fold constants.  No HIP call in here (helper mode).
     const fp inv2 = fp_inv(fp_make(2, 0, 0, 0));
     fp off_inv = fp_inv(off);                      // (off^(2^r))^-1 = (off^-1)^(2^r): one inversion for the whole commit
     std::vector<fp> alpha(B);
-    const bool dbg = getenv("STARK_HIP_DEBUG") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    std::vector<double> t_pub(R, 0.0), t_enq0(R, 0.0), t_enq1(R, 0.0);    // debug: when c0(r) was published; the caller's enqueue after it
     double t_wait = 0, t_host = 0, t_enq = 0;
     uint32_t retries = 0;
     const uint32_t max_retries = 4 * R + 32;
     for (uint32_t r = 0; r < R; ++r) {
         const double t0 = now();
         for (;;) {
-            const int32_t w = wait_seq(c, reinterpret_cast<const uint32_t*>(c->h_chain + lay.root_seq(r)), gen, r, timeout_s);
+            const int32_t w = wait_seq(c, reinterpret_cast<const uint32_t*>(c->h_chain + lay.root_seq(r)), gen, r, timeout_s, helper);
             if (w == SH_OK) break;
+            if (w == WAIT_ENQUEUE_FAILED) { const int32_t rc = helper->wait(&helper_msg); return sh_fail(rc, helper_msg.c_str()); }
             if (w != WAIT_RETRY) return w;
-            // The wait kernel of round r (or of r+1, which then found root r published) ran out of spin before it saw the
-            // challenge: the host was slow (a long callback), or the kernel kept reading a stale copy of the record — seen
-            // when another host thread allocates or frees device memory while the kernel polls; a kernel launched afterwards
-            // reads the fresh value.  Everything behind it on the stream has returned at sight of the abort word, so no
-            // codeword or root of round >= r was written: drain, lower the flags, enqueue again from round r.
+            // The wait kernel of round r (or of r+1, which then found root r published) ran out of spin before the challenge was
+            // there: the transcript callback was slower than the budget, or (inline mode) this thread sat in a launch that was
+            // blocked behind another thread's hipFree.  Everything behind that kernel on the stream has returned at sight of the
+            // abort word, so no codeword or root of round >= r was written: drain, lower the flags, enqueue again from round r.
+            if (dbg) {
+                const volatile uint32_t* hd = h_abort;
+                const uint64_t tk1 = *reinterpret_cast<const volatile uint64_t*>(h_abort + 8), tk0 = *reinterpret_cast<const volatile uint64_t*>(h_abort + 10);
+                const double g1 = cal_host_us + ((double)(int64_t)(tk1 - cal_ticks)) / 100.0 - t_start, g0 = cal_host_us + ((double)(int64_t)(tk0 - cal_ticks)) / 100.0 - t_start;
+                const uint32_t off = hd[3] & 0x7fffffffu;
+                const uint32_t k = (uint32_t)((off - lay.off_c0) / lay.rec_c0);
+                fprintf(stderr, "[stark_hip] GAVE UP: %s waited for c0(%u) (gen %u) from t=%.1f to t=%.1f us (%u polls, xcc %u); it read %u (polling load), %u (non-temporal load), neighbour word %u.\n"
+                                "[stark_hip]   host: c0(%u) %s; now t=%.1f, serving round %u; this thread's last enqueue: round-%u slot, t=%.1f .. %.1f us%s\n",
+                        (hd[3] >> 31) ? "k_round_wg" : "k_wait_c0", k, hd[1], g0, g1, hd[5], hd[6], hd[2], hd[7], hd[14], k,
+                        k < R && t_pub[k] > 0 ? "published at" : "NOT published yet", now() - t_start, r, r ? r - 1 : 0, r ? t_enq0[r - 1] - t_start : 0.0, r ? t_enq1[r - 1] - t_start : 0.0,
+                        helper ? " (enqueue thread in use)" : "");
+                if (k < R && t_pub[k] > 0) fprintf(stderr, "[stark_hip]   c0(%u) published at t=%.1f us: %s the kernel gave up\n", k, t_pub[k] - t_start, t_pub[k] - t_start > g1 ? "AFTER" : "BEFORE");
+            }
             if (++retries > max_retries) return fail_gave_up(c, r, gen, retries - 1);
+            if (helper) { const int32_t rc = helper->wait(&helper_msg); if (rc != SH_OK) return sh_fail(rc, helper_msg.c_str()); }
             HIPCHK(hipStreamSynchronize(c->stream));
             if (__atomic_load_n(reinterpret_cast<const uint32_t*>(c->h_chain + lay.root_seq(r)), __ATOMIC_ACQUIRE) == gen) {
                 // root r did arrive: it was round r+1's wait that gave up; serve root r first, recover on the next wait
                 break;
             }
-            for (int i = 0; i < 8; ++i) __atomic_store_n(h_abort + i, 0u, __ATOMIC_RELAXED);
+            for (int i = 0; i < 12; ++i) __atomic_store_n(h_abort + i, 0u, __ATOMIC_RELAXED);
             c->batch_done_total = 0;
             HIPCHK(hipMemsetAsync(c->d_flag + 16, 0, 4, c->stream));
             HIPCHK(hipMemsetAsync(d_abort, 0, 4, c->stream));
             enq = r;
-            SHCHK(enqueue_round());
-            if (enq < R) SHCHK(enqueue_round());
+            if (helper) helper->post(enqueue_rest);
+            else {
+                SHCHK(enqueue_round());
+                if (enq < R) SHCHK(enqueue_round());
+            }
             if (dbg) fprintf(stderr, "[stark_hip] round %u re-enqueued (%u so far)\n", r, retries);
         }
         const double t1 = now();
@@ -358,17 +428,20 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
                 h_c0[b] = mont_mul(alpha[b], k_rr);                                   // c0 = alpha · 2^-1 · offset_r^-1, in Montgomery form
             }
             __atomic_store_n(reinterpret_cast<uint32_t*>(c->h_chain + lay.c0_seq(r)), gen, __ATOMIC_RELEASE);
+            if (dbg) t_pub[r] = now();
             guard.next_c0 = r + 1;
             off_inv = fp_mul(off_inv, off_inv);
         }
         const double t2 = now();
-        if (enq < R) SHCHK(enqueue_round());
+        if (!helper && enq < R) SHCHK(enqueue_round());
         if (dbg) {
             const double t3 = now();
+            t_enq0[r] = t2; t_enq1[r] = t3;
             t_wait += t1 - t0; t_host += t2 - t1; t_enq += t3 - t2;
             fprintf(stderr, "[stark_hip] round %2u L=2^%-2u  wait root %6.1f us | transcript + c0 %5.1f us | enqueue ahead %5.1f us\n", r, ilog2(N >> r), t1 - t0, t2 - t1, t3 - t2);
         }
     }
+    if (helper) { const int32_t rc = helper->wait(&helper_msg); if (rc != SH_OK) return sh_fail(rc, helper_msg.c_str()); }
     c->chain_retries += retries;
     const fp* cur = R > 1 ? cw_of(R - 1) : d_cws;
     const size_t L = L_last;
@@ -378,7 +451,8 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
     if (*h_abort) return sh_fail(SH_EHIP, "fri_commit: a round timed out on the GPU waiting for its challenge");
     if (stage_last) memcpy(last_out, c->h_chain + lay.off_last, last_bytes);
     *last_len = L;
-    if (dbg) fprintf(stderr, "[stark_hip] commit B=%zu N=2^%u: waited for roots %.0f us, host transcripts %.0f us, enqueue %.0f us over %u rounds\n", B, log_N, t_wait, t_host, t_enq, R);
+    if (dbg) fprintf(stderr, "[stark_hip] commit B=%zu N=2^%u: waited for roots %.0f us, host transcripts %.0f us, enqueue %.0f us over %u rounds%s\n", B, log_N, t_wait, t_host, t_enq, R,
+                     helper ? " (enqueue thread)" : "");
     return SH_OK;
 }
 
@@ -425,9 +499,9 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
         // the two groups stay in phase and the second thread only costs (1.25 -> 1.35 ms), so small batches keep one group.
         static const bool one_group = getenv("STARK_HIP_BATCH_ONE_GROUP") != nullptr;
         const size_t G = (!one_group && B >= 32 && R >= 2 && (B << log_N) >= ((size_t)1 << 23)) ? 2 : 1;
-        if (G == 2 && !c->sub) {
-            SHCHK(sh_ctx_create(c->device, nullptr, &c->sub));
-            HIPCHK(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
+        if (G == 2 && (!c->sub || !c->ev_sync)) {                            // both or neither: a half-made pair would fail every later batch
+            if (!c->ev_sync) HIPCHK(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
+            if (!c->sub) SHCHK(sh_ctx_create(c->device, nullptr, &c->sub));
         }
         unsigned T = std::thread::hardware_concurrency();
         if (T > 8) T = 8;

@@ -100,6 +100,63 @@ class SpinPool {
     unsigned use_ = 1;
 };
 
+// The thread of a context that makes the HIP calls of a commit's rounds (api_fri.hip).  The caller's thread serves the
+// root -> challenge chain and must never sit inside the runtime while a kernel on the GPU waits for it: a launch can block
+// behind another thread's hipFree / context teardown, which itself waits for the device to go idle — i.e. for the very
+// kernel that waits for this host thread.  So the launches go through this thread, which nothing on the
+// GPU depends on.  Asleep on a condition variable between commits.
+class ChainEnqueuer {
+  public:
+    explicit ChainEnqueuer(int device) : device_(device), th_([this] { run(); }) {}
+    ~ChainEnqueuer() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        th_.join();
+    }
+    // job() runs on the helper thread; one job at a time (post, then wait, then post again)
+    void post(std::function<int32_t()> job) {
+        { std::lock_guard<std::mutex> g(m_); job_ = std::move(job); done_.store(false, std::memory_order_relaxed); has_job_ = true; }
+        cv_.notify_one();
+    }
+    bool done() const { return done_.load(std::memory_order_acquire); }
+    bool failed() const { return done() && rc_ != SH_OK; }
+    // blocks until the posted job has returned; its status, and its error text in *msg
+    int32_t wait(std::string* msg) {
+        uint32_t spins = 0;
+        while (!done()) { if (++spins > 2000) std::this_thread::yield(); else __builtin_ia32_pause(); }
+        if (rc_ != SH_OK && msg) *msg = msg_;
+        return rc_;
+    }
+  private:
+    void run() {
+        (void)hipSetDevice(device_);
+        for (;;) {
+            std::function<int32_t()> job;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return stop_ || has_job_; });
+                if (stop_) return;
+                job = std::move(job_);
+                has_job_ = false;
+            }
+            int32_t rc;
+            try { rc = job(); } catch (...) { rc = sh_fail(SH_ENOMEM, "fri_commit: exception in the enqueue thread"); }
+            rc_ = rc;
+            if (rc != SH_OK) msg_ = sh_last_error();
+            done_.store(true, std::memory_order_release);
+        }
+    }
+    int device_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<int32_t()> job_;
+    bool has_job_ = false, stop_ = false;
+    std::atomic<bool> done_{true};
+    int32_t rc_ = SH_OK;
+    std::string msg_;
+    std::thread th_;                             // last member: the thread starts with everything above constructed
+};
+
 // ------------------------------------------------------------------ context
 #define NUM_SCRATCH 16
 enum { SCR_IO_A = 0, SCR_IO_B = 1, SCR_IO_C = 2, SCR_WORK = 3, SCR_DIG_A = 4, SCR_DIG_B = 5, SCR_ROOTS = 6, SCR_C0 = 7,
@@ -128,6 +185,7 @@ struct sh_ctx {
     uint8_t* d_chain = nullptr;                  // device view of h_chain
     size_t chain_bytes = 0;
     SpinPool* pool = nullptr;                    // transcript workers of batched commits (asleep between calls)
+    ChainEnqueuer* enqueuer = nullptr;           // makes the HIP calls of a commit's rounds while the caller serves the chain
     sh_ctx* sub = nullptr;                       // second stream + buffers for the second lock-step group of a batched commit
     hipEvent_t ev_sync = nullptr;                // orders the second stream after the first at the start of a batched commit
     uint8_t* h_query = nullptr;                  // pinned staging of the query phase (paths | values | indices | tree table)

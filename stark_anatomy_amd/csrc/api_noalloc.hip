@@ -1,6 +1,7 @@
 // api_noalloc.hip — the one entry point of the library that allocates nothing: sh_dev_merkle_commit_elems_noalloc.
 //
-// For callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it).
+// For callers that cannot call hipMalloc (tight serving loops, harnesses that forbid allocation).  It allocates nothing but it
+// does wait for the root on the host (mailbox poll, or a copy + stream synchronise), so it is NOT usable under stream capture.
 // It is sh_dev_merkle_commit_elems (api_merkle.hip) with the digest buffers — which that entry point takes from the
 // context's grow-only hipMalloc'ed scratch — placed in a file-scope __device__ array instead.  Same kernels, same root.
 //
@@ -19,16 +20,16 @@
 static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
 
 #define NOALLOC_MAX_DEVICES 64
-static unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+static std::atomic<unsigned char*> g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};   // published once per device; two threads creating contexts may both resolve it (same address)
 
 // Called by sh_ctx_create with `device` current.  Idempotent per device.
 int32_t noalloc_init_device(int device) {
     if (device < 0 || device >= NOALLOC_MAX_DEVICES) return SH_OK;      // no slot: the entry point reports it
-    if (g_scratch_ptr[device]) return SH_OK;
+    if (g_scratch_ptr[device].load(std::memory_order_acquire)) return SH_OK;
     void* p = nullptr;
     HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     if (!p) return sh_fail(SH_EHIP, "hipGetSymbolAddress returned a null address for the no-alloc scratch array");
-    g_scratch_ptr[device] = (unsigned char*)p;
+    g_scratch_ptr[device].store((unsigned char*)p, std::memory_order_release);
     return SH_OK;
 }
 
@@ -39,7 +40,7 @@ extern "C" int32_t sh_dev_merkle_commit_elems_noalloc(sh_ctx* c, const uint64_t*
     const uint32_t lg = ilog2(L);
     if (lg > SH_NOALLOC_MAX_LOG_L)
         return sh_failf(SH_EINVAL, "sh_dev_merkle_commit_elems_noalloc: L = 2^%u exceeds the fixed scratch (max 2^%d elements); use sh_dev_merkle_commit_elems", lg, SH_NOALLOC_MAX_LOG_L);
-    unsigned char* base = (c->device >= 0 && c->device < NOALLOC_MAX_DEVICES) ? g_scratch_ptr[c->device] : nullptr;
+    unsigned char* base = (c->device >= 0 && c->device < NOALLOC_MAX_DEVICES) ? g_scratch_ptr[c->device].load(std::memory_order_acquire) : nullptr;
     if (!base) return sh_fail(SH_EHIP, "sh_dev_merkle_commit_elems_noalloc: scratch array not resolved on this device");
     digest64* bufA = (digest64*)base;
     digest64* bufB = bufA + NOALLOC_A_DIGESTS;

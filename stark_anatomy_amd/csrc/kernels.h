@@ -115,6 +115,8 @@ hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* 
 // from pinned host memory to d_c0.  Gives up after timeout_ticks (100 MHz) and raises *d_abort / *h_abort.
 hipError_t launch_wait_c0(const uint32_t* h_seq, uint32_t gen, const fp* h_c0, fp* d_c0, size_t B, uint32_t* d_abort, uint32_t* h_abort, uint64_t timeout_ticks,
                           hipStream_t s);
+// the device's 100 MHz wall clock (s_memrealtime) into a pinned host word
+hipError_t launch_clock_probe(uint64_t* h_out, hipStream_t s);
 // B digests that are already roots -> pinned host record, then the sequence word
 hipError_t launch_publish_digests(const digest64* in, size_t B, uint64_t* h_roots, uint32_t* h_seq, uint32_t seq, hipStream_t s, const uint32_t* d_abort = nullptr);
 // n elements -> device-mapped pinned host memory (the last codeword of a commit)

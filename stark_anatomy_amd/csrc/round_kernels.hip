@@ -13,6 +13,31 @@
 #include "quad_b2b.cuh"
 
 #define POLL_WORD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+// Post-mortem of a wait that ran out of spin, into the chain header (pinned host memory, 16 words): what was expected, what the
+// record held — read once more with the polling load, with a non-temporal load, and its neighbour word in the same 64-byte
+// line (the host never writes that one: it must read 0) —, where, how many polls, on which XCC, and the 100 MHz wall clock at
+// the start of the spin and now.  The host compares those two stamps with its own record of when it published (api_fri.hip).
+__device__ static void gave_up_record(uint32_t* h_abort, const uint32_t* h_seq, uint32_t gen, uint32_t where, uint32_t polls, uint64_t t0, bool round_wg) {
+    const uint64_t t1 = __builtin_amdgcn_s_memrealtime();
+    __hip_atomic_store(h_abort + 1, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(h_abort + 2, POLL_WORD(h_seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(h_abort + 3, (uint32_t)(reinterpret_cast<uintptr_t>(h_seq) - reinterpret_cast<uintptr_t>(h_abort)) | (round_wg ? 0x80000000u : 0u), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(h_abort + 4, where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(h_abort + 5, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(h_abort + 6, (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(h_abort + 7, __builtin_nontemporal_load(h_seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(h_abort + 8), t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(h_abort + 10), t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(h_abort + 14, POLL_WORD(h_seq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(h_abort, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the device's 100 MHz wall clock into pinned host memory: pairs it with the host's clock (debug runs only)
+__global__ void k_clock_probe(uint64_t* h_out) { __hip_atomic_store(h_out, (uint64_t)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+hipError_t launch_clock_probe(uint64_t* h_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(1), 0, s, h_out);
+    return hipGetLastError();
+}
 // h_seq: pinned host word.  value & 0x7fffffff == gen means "published"; bit 31 = abort.
 __global__ __launch_bounds__(1024) void k_wait_c0(const uint32_t* __restrict__ h_seq, uint32_t gen, const fp* __restrict__ h_c0, fp* __restrict__ d_c0,
                                                   uint32_t B, uint32_t* __restrict__ d_abort, uint32_t* __restrict__ h_abort, uint64_t timeout_ticks) {
@@ -32,15 +57,7 @@ __global__ __launch_bounds__(1024) void k_wait_c0(const uint32_t* __restrict__ h
             }
             if (st) {
                 __hip_atomic_store(d_abort, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (st == 2) {                                              // post-mortem: what was expected, what the record held, where
-                    __hip_atomic_store(h_abort + 1, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(h_abort + 2, __hip_atomic_load(h_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(h_abort + 3, (uint32_t)(reinterpret_cast<uintptr_t>(h_seq) - reinterpret_cast<uintptr_t>(h_abort)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(h_abort + 4, 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(h_abort + 5, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(h_abort + 6, (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(h_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
+                if (st == 2) gave_up_record(h_abort, h_seq, gen, 1u << 16, polls, t0, false);
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);                        // system scope: the c0 loads below come after the poll
@@ -115,15 +132,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_round_wg(const RoundArgs a) {
                 }
                 if (st) {
                     __hip_atomic_store(a.d_abort, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (st == 2) {
-                        __hip_atomic_store(a.h_abort + 1, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        __hip_atomic_store(a.h_abort + 2, __hip_atomic_load(a.h_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        __hip_atomic_store(a.h_abort + 3, (uint32_t)(reinterpret_cast<uintptr_t>(a.h_seq) - reinterpret_cast<uintptr_t>(a.h_abort)) | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        __hip_atomic_store(a.h_abort + 4, blockIdx.x | (gridDim.x << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        __hip_atomic_store(a.h_abort + 5, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        __hip_atomic_store(a.h_abort + 6, (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        __hip_atomic_store(a.h_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
+                    if (st == 2) gave_up_record(a.h_abort, a.h_seq, a.gen, blockIdx.x | (gridDim.x << 16), polls, t0, true);
                 }
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);

@@ -481,15 +481,20 @@ def test_two_contexts_in_two_threads():
                 roots, last = sa.Fri(G, None, 1 << log_n, 4, 17, ctx=c).commit(cw, ps)
                 assert [h.as_bytes() for h in roots] == r and np.array_equal(last, l) and ps.serialize() == ser
                 assert np.array_equal(sa.ntt(cw[: 1 << 12], ctx=c), ntt_exp)
+            retries.append(c.chain_retries)
             c.close()
         except Exception as e:  # surfaced in the main thread
             errors.append(e)
+    retries = []
     th = [threading.Thread(target=worker, args=j) for j in jobs]
     for t in th:
         t.start()
     for t in th:
         t.join()
     assert not errors, errors
+    # the thread that serves a commit's chain makes no HIP call while a kernel waits for it: no wait kernel
+    # may have run out of spin, at the default budget
+    assert retries == [0, 0], retries
 
 
 def test_commit_recovers_when_wait_kernels_run_out_of_spin(monkeypatch):
@@ -528,9 +533,11 @@ def test_commit_recovers_when_wait_kernels_run_out_of_spin(monkeypatch):
 
 
 def test_commit_while_another_thread_allocates_and_frees():
-    """A kernel that polls pinned host memory can keep reading a stale value for as long as it runs when another host
-    thread allocates or frees device memory meanwhile (measured on this stack).  The commit driver must ride
-    that out through its bounded spin + re-launch: commits in one thread, hipMalloc/hipFree churn in another."""
+    """Another host thread's hipFree waits for the device to go idle and meanwhile blocks this thread's launches; a commit
+    thread caught inside a launch could then not publish the challenge that the GPU's wait kernel — which keeps the device
+    busy — was spinning for (round 2 rode that out by bounded spin + re-launch).  The launches now come from
+    the context's enqueue thread and the serving thread makes no HIP call: commits in one thread, hipMalloc/hipFree churn
+    in another, oracle results and NOT ONE re-launch."""
     import threading
     log_n = 15
     cw = co.splitmix_elems(31, 1 << log_n)
@@ -557,11 +564,68 @@ def test_commit_while_another_thread_allocates_and_frees():
             ps = sa.ProofStream()
             roots, last = sa.Fri(G, None, 1 << log_n, 4, 17, ctx=c).commit(cw, ps)
             assert [h.as_bytes() for h in roots] == r and np.array_equal(last, l) and ps.serialize() == ser
+        retries = c.chain_retries
     finally:
         stop.set()
         t.join()
         c.close()
     assert not errors, errors
+    assert retries == 0, f"{retries} rounds were enqueued a second time"
+
+
+def test_commit_after_commit_of_another_shape_on_one_context():
+    """The chain's record layout depends on (B, R), so the sequence words of one commit lie where an earlier commit of
+    another shape staged data.  A one-round commit of N = 128 stages its own codeword in the chain buffer; with every element
+    equal to the NEXT commit's generation number those bytes read as "published" to a driver that does not lower its
+    sequence words first: the larger commit that follows must still produce the oracle's roots."""
+    for first_val in (2, 3):                       # generation of the second / third commit on a fresh context
+        c = sa.Context(0)
+        try:
+            for _ in range(first_val - 1):
+                small = np.zeros((128, 2), dtype=np.uint64)
+                small[:, 0] = first_val
+                ps0 = sa.ProofStream()
+                roots0, last0 = sa.Fri(G, None, 128, 4, 17, ctx=c).commit(small, ps0)
+                assert len(roots0) == 1 and np.array_equal(last0, small)
+            for log_n, B in ((15, 1), (9, 4)):
+                if B == 1:
+                    cw = co.splitmix_elems(77, 1 << log_n)
+                    r, _, l, ps_exp = co.fri_commit(cw, 4, 17, G)
+                    ps = sa.ProofStream()
+                    roots, last = sa.Fri(G, None, 1 << log_n, 4, 17, ctx=c).commit(cw, ps)
+                    assert [h.as_bytes() for h in roots] == r and np.array_equal(last, l) and ps.serialize() == ps_exp.serialize()
+                else:
+                    cws = np.stack([co.splitmix_elems(80 + b, 1 << log_n) for b in range(B)])
+                    streams = [sa.ProofStream() for _ in range(B)]
+                    roots, last = sa.Fri(G, None, 1 << log_n, 4, 17, ctx=c).commit_batch(cws, streams)
+                    for b in range(B):
+                        r, _, l, ps_exp = co.fri_commit(cws[b], 4, 17, G)
+                        assert [h.as_bytes() for h in roots[b]] == r and (last[b] == l).all() and streams[b].serialize() == ps_exp.serialize()
+            assert c.chain_retries == 0
+        finally:
+            c.close()
+
+
+def test_coset_lde_batch_rejects_overlapping_buffers(ctx):
+    """stark_hip.h: in place (d_coeffs == d_out) is defined for one polynomial only; a batch in place, or partially
+    overlapping ranges, would read coefficients that an earlier polynomial's padded output has overwritten -> SH_EINVAL."""
+    import ctypes as C
+    from stark_anatomy_amd._lib import lib, SH_EINVAL
+    from stark_anatomy_amd.context import _u64p, scalar
+    log_n, log_e, B = 10, 2, 3
+    n, N = 1 << log_n, 1 << (log_n + log_e)
+    buf = ctx.alloc(B * N * 16)
+    off = scalar(G)
+    coeffs = co.splitmix_elems(5, n)
+    buf.upload(coeffs)
+    as_p = lambda addr: C.c_void_p(addr)
+    assert lib.sh_dev_coset_lde_batch(ctx.handle, as_p(buf.ptr), B, log_n, log_e, _u64p(off), as_p(buf.ptr)) == SH_EINVAL
+    assert lib.sh_dev_coset_lde_batch(ctx.handle, as_p(buf.ptr + 16 * n), 1, log_n, log_e, _u64p(off), as_p(buf.ptr)) == SH_EINVAL
+    # one polynomial in place stays valid and equals the oracle
+    assert lib.sh_dev_coset_lde_batch(ctx.handle, as_p(buf.ptr), 1, log_n, log_e, _u64p(off), as_p(buf.ptr)) == 0
+    out = buf.download(np.uint64, (N, 2))
+    assert np.array_equal(out, co.coset_lde(coeffs, log_e, G))
+    buf.free()
 
 
 def test_c5_full_size_2_24_vs_oracle(ctx):
