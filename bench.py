@@ -239,6 +239,31 @@ def main():
         extra["batch_128x2^14_ms"] = 1e3 * dt_b / max(5, args.steps)
         d_b.free()
 
+        # ---- throughput at the two sizes the metric names: several resident codewords per call (lock-step groups on two streams,
+        # one group's latency-bound tree tops and hand-offs under the other's wide kernels) ----
+        for Bt, lt in ((8, 20), (2, 24)):
+            if lt > log_n:
+                continue
+            nt = 1 << lt
+            d_t = resident_codeword(Bt * nt, 6000 + lt + rank)
+            Rt = int(_lib.lib.sh_fri_num_rounds(nt, 4, 17))
+            roots_t = np.zeros((Bt, Rt, 64), dtype=np.uint8)
+            last_t = np.empty((Bt, nt >> (Rt - 1), 2), dtype=np.uint64)
+            st = max(4, args.steps // 2)
+            pss = [[sa.ProofStream() for _ in range(Bt)] for _ in range(st + 2)]
+            hs = [(_lib.ps_t * Bt)(*[p.handle for p in row]) for row in pss]
+            it = [0]
+
+            def tp_commit():
+                ll = C.c_size_t(0)
+                h = hs[it[0]]; it[0] += 1
+                _lib.check(_lib.lib.sh_dev_fri_commit_batch(H, d_t.ptr, Bt, nt, C.byref(params), h, _u8p(roots_t), _u64p(last_t), C.byref(ll)))
+            dt_t = timed(tp_commit, st, 2)
+            extra[f"fri_commit_{Bt}x2^{lt}_elems_per_s"] = world * Bt * nt * st / dt_t
+            extra[f"fri_commit_{Bt}x2^{lt}_ms"] = 1e3 * dt_t / st
+            del pss, hs
+            d_t.free()
+
         # ---- the other domain the metric names ----
         other = 20 if log_n != 20 else 24
         d_o = resident_codeword(1 << other, 2000 + rank)

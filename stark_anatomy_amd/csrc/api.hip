@@ -85,7 +85,13 @@ extern "C" {
 const char* sh_last_error(void) { return g_last_error.c_str(); }
 const char* sh_version(void) { return "stark_hip 0.1 (gfx950)"; }
 
-int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out) {
+int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out) { return ctx_create_impl(device, hip_stream, false, out); }
+}  // extern "C"
+// high_priority: the context's own stream comes from the runtime's high-priority queue pool.  Streams share the few hardware
+// queues of the device (GPU_MAX_HW_QUEUES = 4) per priority level, and a kernel that waits for the host holds up whatever
+// another stream has put behind it in the same hardware queue: the second lock-step group of a batched commit asks for the
+// other pool so that its queue is never the one of the caller's (normal-priority) stream (api_fri.hip).
+int32_t ctx_create_impl(int32_t device, void* hip_stream, bool high_priority, sh_ctx** out) {
     if (!out) return sh_fail(SH_EINVAL, "sh_ctx_create: null out");
     *out = nullptr;
     int count = 0;
@@ -105,7 +111,10 @@ int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out) {
     c->device = device;
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else {
-        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        int prio_least = 0, prio_greatest = 0;
+        if (high_priority && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_greatest != prio_least)
+            e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest);
+        else e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete c; return sh_failf(SH_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
@@ -119,6 +128,7 @@ int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out) {
     *out = c;
     return SH_OK;
 }
+extern "C" {
 uint64_t sh_ctx_chain_retries(const sh_ctx* c) { return c ? c->chain_retries + (c->sub ? c->sub->chain_retries : 0) : 0; }
 int32_t sh_ctx_destroy(sh_ctx* c) {
     if (!c) return SH_OK;

@@ -498,10 +498,10 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
         // tops, root hand-off, transcripts) overlap the other's kernels.  Measured: 1024 x 2^14 6.75 -> 6.3 ms; at 128 x 2^14
         // the two groups stay in phase and the second thread only costs (1.25 -> 1.35 ms), so small batches keep one group.
         static const bool one_group = getenv("STARK_HIP_BATCH_ONE_GROUP") != nullptr;
-        const size_t G = (!one_group && B >= 32 && R >= 2 && (B << log_N) >= ((size_t)1 << 23)) ? 2 : 1;
+        const size_t G = (!one_group && B >= 2 && R >= 2 && (B << log_N) >= ((size_t)1 << 23)) ? 2 : 1;   // a few large codewords too: 8 x 2^20, 2 x 2^24
         if (G == 2 && (!c->sub || !c->ev_sync)) {                            // both or neither: a half-made pair would fail every later batch
             if (!c->ev_sync) HIPCHK(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
-            if (!c->sub) SHCHK(sh_ctx_create(c->device, nullptr, &c->sub));
+            if (!c->sub) SHCHK(ctx_create_impl(c->device, nullptr, true, &c->sub));      // its stream: the other priority pool, never the caller's hardware queue
         }
         unsigned T = std::thread::hardware_concurrency();
         if (T > 8) T = 8;

@@ -37,64 +37,79 @@
         HIPCHK(hipSetDevice((c)->device));                                 \
     } while (0)
 
-// Worker threads of a context that are handed one slice of the B transcripts of a batched commit per round.  Awake, they
-// spin (then yield) between rounds: a round's hand-off must cost well under the ~10 us a wake-up does.  Between calls
-// they sleep on a condition variable.
+// Worker threads of a context that are handed one slice of the B transcripts of a batched commit per round.  Between wake(use)
+// and park() the first use - 1 of them spin (then yield) between rounds: a round's hand-off must cost well under the ~10 us a
+// wake-up does.  The others, and all of them between calls, sleep on a condition variable: a spinning thread that has no slice
+// to work on only takes a core from the threads that serve the chains (the box gives a process 16; two lock-step groups with
+// seven idle spinners each ran 2.4 - 7 ms per 8 x 2^20 batch, call by call).
 class SpinPool {
   public:
     explicit SpinPool(unsigned workers) {
         for (unsigned w = 0; w < workers; ++w) th_.emplace_back([this, w] { run(w); });
     }
     ~SpinPool() {
-        { std::lock_guard<std::mutex> g(m_); stop_.store(true, std::memory_order_relaxed); awake_.store(true, std::memory_order_release); }
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; awake_.store(false, std::memory_order_release); }
         cv_.notify_all();
-        gen_.fetch_add(1, std::memory_order_release);
         for (auto& t : th_) t.join();
     }
     // `use` threads (the caller included) share the work until park()
     void wake(unsigned use) {
-        use_ = use < 1 ? 1 : (use > th_.size() + 1 ? (unsigned)th_.size() + 1 : use);
-        { std::lock_guard<std::mutex> g(m_); awake_.store(true, std::memory_order_release); }
-        cv_.notify_all();
+        {
+            std::lock_guard<std::mutex> g(m_);
+            use_ = use < 1 ? 1 : (use > th_.size() + 1 ? (unsigned)th_.size() + 1 : use);
+            base_gen_ = gen_.load(std::memory_order_relaxed);
+            awake_.store(true, std::memory_order_release);
+        }
+        if (use_ > 1) cv_.notify_all();
     }
     void park() { awake_.store(false, std::memory_order_release); }
     // f(b0, b1) over [0, n) split into `use` contiguous slices; the caller takes the first
     template <class F>
     void parallel(size_t n, F&& f) {
-        const size_t T = use_, chunk = (n + T - 1) / T;
+        const size_t T = use_;
+        if (T <= 1) { f((size_t)0, n); return; }
+        const size_t chunk = (n + T - 1) / T;
         std::function<void(size_t, size_t)> fn = f;
         fn_ = &fn; n_ = n; chunk_ = chunk;
-        pending_.store((int)th_.size(), std::memory_order_relaxed);
+        pending_.store((int)T - 1, std::memory_order_relaxed);
         gen_.fetch_add(1, std::memory_order_release);
         fn(0, chunk < n ? chunk : n);
         while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
     }
   private:
     void run(unsigned w) {
-        uint64_t seen = 0;
         for (;;) {
-            uint32_t spins = 0;
-            while (gen_.load(std::memory_order_acquire) == seen) {
-                if (!awake_.load(std::memory_order_acquire)) {
-                    std::unique_lock<std::mutex> g(m_);
-                    cv_.wait(g, [this, seen] { return awake_.load(std::memory_order_acquire) || gen_.load(std::memory_order_acquire) != seen; });
-                    spins = 0;
-                } else if (++spins > 4000) std::this_thread::yield();
-                else __builtin_ia32_pause();
+            uint64_t seen;
+            {   // asleep until a call wants this worker; jobs are counted from the generation at that call's wake()
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this, w] { return stop_ || (awake_.load(std::memory_order_acquire) && w + 1 < use_); });
+                if (stop_) return;
+                seen = base_gen_;
             }
-            ++seen;
-            if (stop_.load(std::memory_order_relaxed)) return;
-            const size_t b0 = (size_t)(w + 1) * chunk_, b1 = b0 + chunk_;
-            if (w + 1 < use_) (*fn_)(b0 < n_ ? b0 : n_, b1 < n_ ? b1 : n_);
-            pending_.fetch_sub(1, std::memory_order_release);
+            for (;;) {
+                uint32_t spins = 0;
+                bool parked = false;
+                while (gen_.load(std::memory_order_acquire) == seen) {
+                    if (!awake_.load(std::memory_order_acquire)) { parked = true; break; }
+                    if (++spins > 4000) std::this_thread::yield();
+                    else __builtin_ia32_pause();
+                }
+                if (parked) break;
+                ++seen;
+                const size_t b0 = (size_t)(w + 1) * chunk_, b1 = b0 + chunk_;
+                (*fn_)(b0 < n_ ? b0 : n_, b1 < n_ ? b1 : n_);
+                pending_.fetch_sub(1, std::memory_order_release);
+            }
         }
     }
     std::vector<std::thread> th_;
     std::mutex m_;
     std::condition_variable cv_;
     std::atomic<uint64_t> gen_{0};
+    uint64_t base_gen_ = 0;
     std::atomic<int> pending_{0};
-    std::atomic<bool> stop_{false}, awake_{false};
+    std::atomic<bool> awake_{false};
+    bool stop_ = false;
     const std::function<void(size_t, size_t)>* fn_ = nullptr;
     size_t n_ = 0, chunk_ = 0;
     unsigned use_ = 1;
@@ -211,6 +226,7 @@ static inline fp host_root_of_unity(uint32_t log_n) {
 #define QUAD_MAX_LOG_COUNT 17                  // from this many digests down a tree is reduced four-lanes-per-compression
 
 // api.hip
+int32_t ctx_create_impl(int32_t device, void* hip_stream, bool high_priority, sh_ctx** out);
 int32_t ensure_scratch(sh_ctx* c, int slot, size_t bytes, void** out);
 int32_t get_twiddles(sh_ctx* c, uint32_t log_n, bool inverse, const fp** out);
 int32_t get_pass_tables(sh_ctx* c, const NttPlan& plan, bool inverse, const fp* tw, NttPassTables* out);

@@ -183,66 +183,68 @@ __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const 
     store_digest(digests + i, d);
 }
 
-// K = 3 form of the same kernel with HBM access staged through LDS.  In the plain form lane i reads lo[8i+q], hi[8i+q] and
-// writes out[8i+q] one q at a time, 128 bytes apart from its neighbours: every 128-byte line is touched 8 times over the
-// ~100 us a subtree takes, the lines in flight per XCD (~6 MB) overflow its 4 MB L2, and rocprof shows 4x the algorithmic
-// read traffic (2x for writes).  Here a wave first FOLDS its 512 outputs in coalesced order — lane l takes outputs
-// l, 64+l, ...: one coalesced 1 KB read of each half, the fold, one coalesced 1 KB write of the result per step — and parks
-// the results in LDS (rows of 8 padded to 9 so the later per-lane reads spread over the banks); then every lane hashes its
-// own 8 consecutive results out of LDS.  9.2 KB of LDS per wave, so the kernel runs as many waves as its registers allow
-// (4 per SIMD); the first staged form kept both input halves in LDS (18.4 KB per wave), ran 2 waves per SIMD and was ~10 %
+// The same kernel with HBM access staged through LDS (K = 1, 2, 3).  In the plain form lane i reads lo[2^K·i+q], hi[2^K·i+q] and
+// writes out[2^K·i+q] one q at a time, 2^K·16 bytes apart from its neighbours: every 128-byte line is touched up to 8 times over
+// the ~100 us a subtree takes, the lines in flight per XCD (~6 MB) overflow its 4 MB L2, and rocprof shows 4x the algorithmic
+// read traffic at K = 3 (2x for writes), 1.24x at K = 1, 2.  Here a wave first FOLDS its 64·2^K outputs in coalesced order —
+// lane l takes outputs l, 64+l, ...: one coalesced 1 KB read of each half, the fold, one coalesced 1 KB write of the result per
+// step — and parks the results in LDS (rows of 2^K padded by one so the later per-lane reads spread over the banks); then every
+// lane hashes its own 2^K consecutive results out of LDS.  <= 9.2 KB of LDS per wave, so the kernel runs as many waves as its
+// registers allow; the first staged form kept both input halves in LDS (18.4 KB per wave), ran 2 waves per SIMD and was ~10 %
 // slower for it.
-#define STAGE_ROW 9
-#define STAGE_WAVE_ELEMS (64 * STAGE_ROW)
+template <int K>
 __global__ __launch_bounds__(256, 2) void k_fold_leaf_subtree_staged(const fp* __restrict__ cw, uint32_t log_half, const fp* __restrict__ c0_arr, fp c0_single,
                                                                      const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
                                                                      fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out,
                                                                      const uint32_t* __restrict__ d_abort) {
-    __shared__ fp s_v[4 * STAGE_WAVE_ELEMS];
+    constexpr uint32_t ROW = (1u << K) + 1, WAVE_ELEMS = 64 * ROW;
+    __shared__ fp s_v[4 * WAVE_ELEMS];
     if (d_abort && __hip_atomic_load(d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // n_out is a multiple of 64: whole waves are in or out
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // n_out is a multiple of 256: whole workgroups are in or out
     if (i >= n_out) return;
     const size_t half = (size_t)1 << log_half;
-    const size_t wj0 = (i - lane) << 3;                                        // first output of this wave
+    const size_t wj0 = (i - lane) << K;                                        // first output of this wave
     const size_t b = wj0 >> log_half, ww0 = wj0 & (half - 1);
     const fp c0_mont = c0_arr ? c0_arr[b] : c0_single;
     const fp* lo = cw + (b << (log_half + 1)) + ww0;
     const fp* hi = lo + half;
-    fp* mine = s_v + wave * STAGE_WAVE_ELEMS;
+    fp* mine = s_v + wave * WAVE_ELEMS;
 #pragma unroll 2
-    for (uint32_t t = 0; t < 8; ++t) {
+    for (uint32_t t = 0; t < (1u << K); ++t) {
         const uint32_t e = t * 64 + lane;
         const fp tw = mont_mul(load_tw(tw_inv, log_n_table, (ww0 + e) << tw_shift), c0_mont);
         const fp v = fold_one(lo[e], hi[e], tw);
         out[wj0 + e] = v;
-        mine[e + (e >> 3)] = v;
+        mine[e + (e >> K)] = v;
     }
     __syncthreads();
-    digest64 d = subtree_reduce<3>(3, [&](uint32_t q) {
-        const fp v = mine[lane * STAGE_ROW + q];
+    digest64 d = subtree_reduce<K>(K, [&](uint32_t q) {
+        const fp v = mine[lane * ROW + q];
         return b2b_leaf(fp_lo64(v), fp_hi64(v));
     });
     store_digest(digests + i, d);
 }
 
-// The same staging for the first round's leaf-only kernel (K = 3): one coalesced 8 KB read per wave instead of 8 strided
-// passes over it (rocprof: 341 MB fetched per 268 MB of codeword in the plain form).
+// The same staging for the first round's leaf-only kernel: one coalesced read of the wave's 64·2^K elements instead of 2^K
+// strided passes over them (rocprof at K = 3: 341 MB fetched per 268 MB of codeword in the plain form).
+template <int K>
 __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_leaf_subtree_staged(const fp* __restrict__ elems, digest64* __restrict__ out, size_t n_out) {
-    __shared__ fp s_el[4 * STAGE_WAVE_ELEMS];
+    constexpr uint32_t ROW = (1u << K) + 1, WAVE_ELEMS = 64 * ROW;
+    __shared__ fp s_el[4 * WAVE_ELEMS];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
-    const fp* base = elems + ((i - lane) << 3);
-    fp* mine = s_el + wave * STAGE_WAVE_ELEMS;
+    const fp* base = elems + ((i - lane) << K);
+    fp* mine = s_el + wave * WAVE_ELEMS;
 #pragma unroll
-    for (uint32_t t = 0; t < 8; ++t) {
+    for (uint32_t t = 0; t < (1u << K); ++t) {
         const uint32_t e = t * 64 + lane;
-        mine[e + (e >> 3)] = base[e];
+        mine[e + (e >> K)] = base[e];
     }
     __syncthreads();
-    digest64 d = subtree_reduce<3>(3, [&](uint32_t q) {
-        fp e = mine[lane * STAGE_ROW + q];
+    digest64 d = subtree_reduce<K>(K, [&](uint32_t q) {
+        fp e = mine[lane * ROW + q];
         return b2b_leaf(fp_lo64(e), fp_hi64(e));
     });
     store_digest(out + i, d);
@@ -262,8 +264,11 @@ hipError_t launch_leaf_subtree(const fp* elems, digest64* out, size_t n_out, uin
     if (!n_out) return hipSuccess;
     if (K > SUBTREE_KMAX) return hipErrorInvalidValue;
     static const bool no_stage = getenv("STARK_NO_STAGE") != nullptr;
-    if (K == 3 && (n_out & 255) == 0 && !no_stage) {
-        hipLaunchKernelGGL(k_leaf_subtree_staged, dim3((unsigned)(n_out >> 8)), dim3(256), 0, s, elems, out, n_out);
+    if (K >= 1 && K <= 3 && (n_out & 255) == 0 && !no_stage) {
+        const dim3 grid((unsigned)(n_out >> 8));
+        if (K == 3) hipLaunchKernelGGL(k_leaf_subtree_staged<3>, grid, dim3(256), 0, s, elems, out, n_out);
+        else if (K == 2) hipLaunchKernelGGL(k_leaf_subtree_staged<2>, grid, dim3(256), 0, s, elems, out, n_out);
+        else hipLaunchKernelGGL(k_leaf_subtree_staged<1>, grid, dim3(256), 0, s, elems, out, n_out);
         return hipGetLastError();
     }
     if (K <= 3) hipLaunchKernelGGL(k_leaf_subtree<3>, dim3(grid_for(n_out, 256)), dim3(256), 0, s, elems, out, n_out, K);
@@ -296,9 +301,11 @@ hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* 
     while (((size_t)1 << log_half) < half) ++log_half;
     const size_t n_out = (B * half) >> K;
     static const bool no_stage = getenv("STARK_NO_STAGE") != nullptr;
-    if (K == 3 && (n_out & 255) == 0 && log_half >= 9 && !no_stage) {          // whole 256-lane workgroups, waves inside one codeword
-        hipLaunchKernelGGL(k_fold_leaf_subtree_staged, dim3((unsigned)(n_out >> 8)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
-                           log_n_table, tw_shift, out, digests, n_out, d_abort);
+    if (K >= 1 && K <= 3 && (n_out & 255) == 0 && log_half >= 6 + K && !no_stage) {          // whole 256-lane workgroups, waves inside one codeword
+        const dim3 grid((unsigned)(n_out >> 8));
+        if (K == 3) hipLaunchKernelGGL(k_fold_leaf_subtree_staged<3>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort);
+        else if (K == 2) hipLaunchKernelGGL(k_fold_leaf_subtree_staged<2>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort);
+        else hipLaunchKernelGGL(k_fold_leaf_subtree_staged<1>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort);
         return hipGetLastError();
     }
     if (K <= 3) hipLaunchKernelGGL(k_fold_leaf_subtree<3>, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,

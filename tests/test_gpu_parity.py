@@ -399,10 +399,11 @@ def test_fri_commit_2_24_properties(ctx):
 
 
 # ------------------------------------------------------------------ batched commits (BASELINE config 4)
-@pytest.mark.parametrize("B,log_n", [(1, 10), (3, 7), (8, 14), (128, 14), (5, 1), (2, 18), (8, 19), (4, 22)])
+@pytest.mark.parametrize("B,log_n", [(1, 10), (3, 7), (8, 14), (128, 14), (5, 1), (2, 18), (8, 19), (8, 20), (3, 22), (4, 22)])
 def test_fri_commit_batch_vs_oracle(ctx, B, log_n):
     """B lock-step commits == B separate oracle commits: roots, last codewords and every proof stream's bytes.
-    (8, 19) and (4, 22) reach the LDS-staged K = 3 kernels with per-codeword fold constants."""
+    (8, 19) and (4, 22) reach the LDS-staged K = 3 kernels with per-codeword fold constants; (8, 20), (3, 22) and (4, 22) run as
+    two lock-step groups on two streams (B·N >= 2^23), (3, 22) with groups of unequal size."""
     co.set_threads(16)
     N = 1 << log_n
     cws = np.stack([co.splitmix_elems(1000 + b, N) for b in range(B)])
@@ -424,6 +425,29 @@ def test_fri_commit_batch_vs_oracle(ctx, B, log_n):
     assert (last2 == last).all() and all(a.serialize() == b_.serialize() for a, b_ in zip(streams, streams2))
     d.free()
     co.set_threads(1)
+
+
+def test_two_codewords_of_2_24_as_two_groups(ctx):
+    """2 x 2^24 (bench.py's throughput leg at the metric's large size): the batch call runs the two commits as two groups of
+    one on two streams; roots, last codewords and stream bytes must equal two single commits of the same device data (the
+    single 2^24 commit is oracle-checked in test_c5_full_size_2_24_vs_oracle)."""
+    log_n = 24
+    N = 1 << log_n
+    d = ctx.alloc(2 * N * 16)
+    for b in range(2):
+        cw = co.splitmix_elems(8100 + b, N)
+        _lib.check(_lib.lib.sh_dev_upload(ctx.handle, d.ptr + b * N * 16, cw.ctypes.data, N * 16))
+        del cw
+    fri = sa.Fri(G, None, N, 4, 17, ctx=ctx)
+    streams = [sa.ProofStream() for _ in range(2)]
+    roots, last = fri.commit_batch(d, streams)
+    for b in range(2):
+        ps = sa.ProofStream()
+        r1, l1 = fri.commit(d.ptr + b * N * 16, ps)
+        assert [h.as_bytes() for h in roots[b]] == [h.as_bytes() for h in r1]
+        assert np.array_equal(last[b], l1) and streams[b].serialize() == ps.serialize()
+    assert ctx.chain_retries == 0
+    d.free()
 
 
 def test_large_batch_runs_as_two_groups(ctx):
