@@ -277,6 +277,60 @@ int32_t sh_fri_commit_batch(sh_ctx* ctx, const uint64_t* codewords, size_t B, si
 int32_t sh_dev_fri_commit_batch(sh_ctx* ctx, const uint64_t* d_codewords, size_t B, size_t N, const sh_fri_params* params,
                                 sh_proofstream** streams, uint8_t* roots_out, uint64_t* last_codewords_out, size_t* last_len);
 
+/* ---------------- ONE transform / ONE commit over the P GPUs of a node (BASELINE.json config 5) ----------------
+ * No counterpart in the reference (a single-threaded CPU crate).  One process (or host thread) per GPU, each with its own sh_ctx;
+ * every rank makes the same sh_dist_* call with its own slice.  A vector of n elements lies across the ranks in natural order:
+ * rank g holds elements [g·n/P, (g+1)·n/P).  P must be a power of two.
+ *
+ * Transport = how ranks exchange DEVICE buffers.  sh_dist_create binds it to RCCL (grouped ncclSend/ncclRecv and ncclAllGather
+ * over xGMI on the context's stream; librccl is dlopen()ed on first use — STARK_HIP_RCCL_PATH overrides the search): rank 0 calls
+ * sh_dist_unique_id, hands the 128 bytes to the other ranks by its own means (the Rust host: MPI, a file, torch.distributed …),
+ * every rank calls sh_dist_create with them (a collective call, like ncclCommInitRank).  sh_dist_create_with_transport takes the
+ * three operations from the host instead; each must order itself after the work already enqueued on `hip_stream` and leave the
+ * stream ordered after its own completion (it may simply synchronise), returns 0 on success, and is called from a library thread. */
+#define SH_DIST_ID_BYTES 128
+typedef struct sh_dist sh_dist;
+typedef struct { int32_t peer; int32_t is_send; void* d_buf; size_t bytes; } sh_p2p_op;
+typedef struct {
+    void* user;
+    /* block s (bytes_per_rank bytes at d_send + s·bytes_per_rank) goes to rank s; rank s's block for this rank lands at d_recv + s·bytes_per_rank */
+    int32_t (*all_to_all)(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
+    /* every rank's `bytes` bytes at d_send, concatenated in rank order at d_recv */
+    int32_t (*all_gather)(void* user, const void* d_send, void* d_recv, size_t bytes, void* hip_stream);
+    /* n_ops point-to-point transfers as one group (never to or from this rank itself) */
+    int32_t (*sendrecv)(void* user, const sh_p2p_op* ops, size_t n_ops, void* hip_stream);
+} sh_dist_transport;
+int32_t sh_dist_unique_id(uint8_t id[SH_DIST_ID_BYTES]);
+int32_t sh_dist_create(sh_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[SH_DIST_ID_BYTES], sh_dist** out);
+int32_t sh_dist_create_with_transport(sh_ctx* ctx, int32_t rank, int32_t world, const sh_dist_transport* transport, sh_dist** out);
+int32_t sh_dist_destroy(sh_dist* d);                                         /* before the context it was made on */
+int32_t sh_dist_rank(const sh_dist* d, int32_t* rank, int32_t* world);
+/* all three operations of the transport on small known buffers, checked on the host (run once after creation) */
+int32_t sh_dist_selftest(sh_dist* d);
+/* Four-step NTT of the 2^log_n-point vector whose slice this rank holds: n = n1·n2 (n1 = 2^(log_n/2)), three all-to-all
+ * transposes, batched local transforms and the w_n^(j2·k1) twiddle between them.  One rank: the direct transform.
+ * input_layout  SH_DIST_NATURAL: d_local = x[g·n/P ..);  SH_DIST_IN_COLUMNS: d_local[c][j1] = x[j1·n2 + g·n2/P + c] (skips the first exchange).
+ * output_layout SH_DIST_NATURAL: d_out = X[g·n/P ..);    SH_DIST_OUT_ROWS: d_out[k1l][k2] = X[g·n1/P + k1l + n1·k2] (skips the last one).
+ * d_out may be d_local.  n1 and n2 must be multiples of P. */
+#define SH_DIST_NATURAL 0
+#define SH_DIST_IN_COLUMNS 1
+#define SH_DIST_OUT_ROWS 1
+int32_t sh_dist_ntt(sh_dist* d, const uint64_t* d_local, uint32_t log_n, int32_t inverse, int32_t input_layout, int32_t output_layout, uint64_t* d_out);
+/* coset LDE (G7) of a polynomial whose 2^log_n coefficients lie across the ranks: this rank's natural-order slice of the
+ * 2^(log_n+log_expansion) evaluations f(offset·w^i) into d_out (N/P elements; must not alias the input).  Only the coefficient
+ * slices move (point to point, rank s -> rank s >> log_expansion); the zero padding is laid down locally. */
+int32_t sh_dist_coset_lde(sh_dist* d, const uint64_t* d_local_coeffs, uint32_t log_n, uint32_t log_expansion, const uint64_t offset[2], uint64_t* d_out);
+/* the ranks' slices of `count` elements each, concatenated in rank order, on every rank */
+int32_t sh_dist_all_gather(sh_dist* d, const uint64_t* d_local, size_t count, uint64_t* d_out);
+/* FRI commit of ONE codeword of N elements lying across the ranks (d_local: N/P elements).  Every rank passes its own, identical
+ * ProofStream replica and gets identical roots (R x 64 bytes), last codeword and stream (as sh_dev_fri_commit_proofstream on the
+ * gathered codeword, byte for byte).  Rounds run sharded — fold fused with the next round's leaf hashing on each rank's
+ * half-slices, one 64-byte all-gather of sub-roots and one point-to-point regroup per round — while a rank's half-slice holds at
+ * least min_half elements (0 = default 2^16); then the codeword is all-gathered and every rank finishes the remaining rounds
+ * with the single-GPU driver.  A rank that falls more than STARK_HIP_CHAIN_TIMEOUT_S (default 20 s) behind fails the commit. */
+int32_t sh_dist_fri_commit(sh_dist* d, const uint64_t* d_local, size_t N, const sh_fri_params* params, sh_proofstream* ps, size_t min_half,
+                           uint8_t* roots_out, uint64_t* last_codeword_out, size_t* last_len);
+
 /* ---------------- host-only scalar helpers (no GPU involved; used by the driver and the shim) ---------------- */
 int32_t sh_sha256(const uint8_t* in, size_t len, uint8_t out[32]);                      /* crate sha2, proof_stream.rs:52-55 */
 int32_t sh_blake2b512(const uint8_t* in, size_t len, uint8_t out[64]);                  /* crate blake2, merkle.rs:134-136   */

@@ -46,6 +46,21 @@ class FriParams(C.Structure):
 
 
 TRANSCRIPT_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32, u8p, C.c_int32, u64p)
+dist_t = C.c_void_p
+
+
+class P2POp(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("is_send", C.c_int32), ("d_buf", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+ALL_TO_ALL_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_GATHER_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+SENDRECV_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(P2POp), C.c_size_t, C.c_void_p)
+
+
+class DistTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_to_all", ALL_TO_ALL_CB), ("all_gather", ALL_GATHER_CB), ("sendrecv", SENDRECV_CB)]
+
 
 _PROTOS = {
     "sh_last_error": (C.c_char_p, []),
@@ -130,6 +145,16 @@ _PROTOS = {
     "sh_dev_fri_prove": (C.c_int32, [ctx_t, C.c_void_p, C.c_size_t, C.POINTER(FriParams), ps_t, u64p, szp]),
     "sh_fri_proof_format": (C.c_char_p, []),
     "sh_fri_verify": (C.c_int32, [ps_t, C.c_size_t, C.POINTER(FriParams), C.POINTER(C.c_int32), u64p, szp]),
+    "sh_dist_unique_id": (C.c_int32, [u8p]),
+    "sh_dist_create": (C.c_int32, [ctx_t, C.c_int32, C.c_int32, u8p, C.POINTER(dist_t)]),
+    "sh_dist_create_with_transport": (C.c_int32, [ctx_t, C.c_int32, C.c_int32, C.POINTER(DistTransport), C.POINTER(dist_t)]),
+    "sh_dist_destroy": (C.c_int32, [dist_t]),
+    "sh_dist_rank": (C.c_int32, [dist_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sh_dist_selftest": (C.c_int32, [dist_t]),
+    "sh_dist_ntt": (C.c_int32, [dist_t, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sh_dist_coset_lde": (C.c_int32, [dist_t, C.c_void_p, C.c_uint32, C.c_uint32, u64p, C.c_void_p]),
+    "sh_dist_all_gather": (C.c_int32, [dist_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sh_dist_fri_commit": (C.c_int32, [dist_t, C.c_void_p, C.c_size_t, C.POINTER(FriParams), ps_t, C.c_size_t, u8p, u64p, szp]),
     "sh_sha256": (C.c_int32, [C.c_char_p, C.c_size_t, u8p]),
     "sh_blake2b512": (C.c_int32, [C.c_char_p, C.c_size_t, u8p]),
     "sh_merkle_verify": (C.c_int32, [u8p, u8p, u8p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int32)]),

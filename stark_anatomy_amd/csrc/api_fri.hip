@@ -10,29 +10,8 @@ int32_t check_params(const sh_fri_params* p, fp* offset) {
     if (!fp_is_canonical(*offset) || fp_is_zero(*offset)) return sh_fail(SH_EINVAL, "fri: offset must be a non-zero canonical field element");
     return SH_OK;
 }
-// ------------------------------------------------------------------ the commit chain
-// One pinned, device-mapped buffer per context carries the serial chain of a commit between GPU and host:
-//   header (64 B: word 0 = abort status written by a wait kernel that timed out)
-//   R root records  : B roots (64 B each) | 64-byte line whose first word is the sequence number
-//   R c0 records    : B fold constants (16 B each, Montgomery form), padded to 64 | sequence line
-//   staging for the B last codewords
-// A sequence word equal to the commit's generation number means "published"; bit 31 on a c0 record means "abort".
-struct ChainLayout {
-    size_t B, R, rec_root, rec_c0, off_root, off_c0, off_last, total;
-    ChainLayout(size_t B_, size_t R_, size_t last_bytes) : B(B_), R(R_) {
-        rec_root = B * 64 + 64;
-        rec_c0 = ((B * 16 + 63) & ~(size_t)63) + 64;
-        off_root = 64;
-        off_c0 = off_root + R * rec_root;
-        off_last = off_c0 + R * rec_c0;
-        total = off_last + last_bytes;
-    }
-    size_t roots(size_t r) const { return off_root + r * rec_root; }
-    size_t root_seq(size_t r) const { return roots(r) + B * 64; }
-    size_t c0(size_t r) const { return off_c0 + r * rec_c0; }
-    size_t c0_seq(size_t r) const { return c0(r) + rec_c0 - 64; }
-};
-static int32_t ensure_chain(sh_ctx* c, size_t bytes) {
+// ------------------------------------------------------------------ the commit chain (ChainLayout, ChainGuard: api_internal.h)
+int32_t ensure_chain(sh_ctx* c, size_t bytes) {
     if (c->chain_bytes >= bytes) return SH_OK;
     if (c->h_chain) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->h_chain)); c->h_chain = nullptr; c->d_chain = nullptr; c->chain_bytes = 0; }
     const size_t want = (bytes + 4095) & ~(size_t)4095;
@@ -42,26 +21,12 @@ static int32_t ensure_chain(sh_ctx* c, size_t bytes) {
     c->chain_bytes = want;
     return SH_OK;
 }
-// Releases the GPU on every exit path once kernels that wait for the host are in flight: publishes "abort" in every c0
-// record not yet published and drains the stream.
-struct ChainGuard {
-    sh_ctx* c; const ChainLayout* lay; uint32_t gen; size_t next_c0 = 0, waits = 0; bool armed = false;   // waits: c0 records 0..waits-1 may have a kernel waiting
-    ChainEnqueuer* helper = nullptr;               // a posted job refers to the caller's frame: it must have returned before the frame goes
-    ~ChainGuard() {
-        if (!armed) return;
-        for (size_t r = next_c0; r < waits; ++r)
-            __atomic_store_n(reinterpret_cast<uint32_t*>(c->h_chain + lay->c0_seq(r)), gen | 0x80000000u, __ATOMIC_RELEASE);
-        if (helper) (void)helper->wait(nullptr);
-        (void)hipStreamSynchronize(c->stream);
-    }
-};
 // Wait for a root record.  NO HIP call on this path: while the host sits here the next round's kernel may already be spinning
 // on the GPU for the challenge this thread is about to produce, and a runtime call can block behind another thread's call
 // that itself waits for GPU work queued behind that spinning kernel (seen with two contexts in two threads).  So: poll the
 // record, the abort word that a wait kernel raises when its bounded spin runs out, and a wall clock.
 // Returns SH_OK, WAIT_RETRY (a wait kernel gave up: the caller re-enqueues from this round) or an error.
-static const int32_t WAIT_RETRY = 1, WAIT_ENQUEUE_FAILED = 2;
-static int32_t wait_seq(sh_ctx* c, const uint32_t* flag, uint32_t gen, uint32_t round, double deadline_s, const ChainEnqueuer* helper) {
+int32_t wait_seq(sh_ctx* c, const uint32_t* flag, uint32_t gen, uint32_t round, double deadline_s, const ChainEnqueuer* helper) {
     const volatile uint32_t* hd = reinterpret_cast<volatile uint32_t*>(c->h_chain);
     const auto t0 = std::chrono::steady_clock::now();
     uint64_t spins = 0;

@@ -173,9 +173,10 @@ class ChainEnqueuer {
 };
 
 // ------------------------------------------------------------------ context
-#define NUM_SCRATCH 16
+#define NUM_SCRATCH 20
 enum { SCR_IO_A = 0, SCR_IO_B = 1, SCR_IO_C = 2, SCR_WORK = 3, SCR_DIG_A = 4, SCR_DIG_B = 5, SCR_ROOTS = 6, SCR_C0 = 7,
-       SCR_ARENA = 8, SCR_LEVELS = 9, SCR_IDX = 10, SCR_PATHS = 11, SCR_POLY_A = 12, SCR_POLY_B = 13, SCR_LDE_TAB = 14, SCR_BINV = 15 };
+       SCR_ARENA = 8, SCR_LEVELS = 9, SCR_IDX = 10, SCR_PATHS = 11, SCR_POLY_A = 12, SCR_POLY_B = 13, SCR_LDE_TAB = 14, SCR_BINV = 15,
+       SCR_DIST_A = 16, SCR_DIST_B = 17, SCR_DIST_C = 18, SCR_DIST_SUB = 19 };
 struct sh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -240,6 +241,46 @@ int32_t fetch_root(sh_ctx* c, uint8_t root[64]);
 // api_noalloc.hip
 int32_t noalloc_init_device(int device);
 // api_fri.hip
+// ---- the commit chain (api_fri.hip; shared with the sharded commit, api_dist.hip)
+// One pinned, device-mapped buffer per context carries the serial chain of a commit between GPU and host:
+//   header (64 B: word 0 = abort status written by a wait kernel that timed out)
+//   R root records  : B roots (64 B each) | 64-byte line whose first word is the sequence number
+//   R c0 records    : B fold constants (16 B each, Montgomery form), padded to 64 | sequence line
+//   staging for the B last codewords
+// A sequence word equal to the commit's generation number means "published"; bit 31 on a c0 record means "abort".
+struct ChainLayout {
+    size_t B, R, rec_root, rec_c0, off_root, off_c0, off_last, total;
+    ChainLayout(size_t B_, size_t R_, size_t last_bytes) : B(B_), R(R_) {
+        rec_root = B * 64 + 64;
+        rec_c0 = ((B * 16 + 63) & ~(size_t)63) + 64;
+        off_root = 64;
+        off_c0 = off_root + R * rec_root;
+        off_last = off_c0 + R * rec_c0;
+        total = off_last + last_bytes;
+    }
+    size_t roots(size_t r) const { return off_root + r * rec_root; }
+    size_t root_seq(size_t r) const { return roots(r) + B * 64; }
+    size_t c0(size_t r) const { return off_c0 + r * rec_c0; }
+    size_t c0_seq(size_t r) const { return c0(r) + rec_c0 - 64; }
+};
+// Releases the GPU on every exit path once kernels that wait for the host are in flight: publishes "abort" in every c0
+// record not yet published and drains the stream.
+struct ChainGuard {
+    sh_ctx* c; const ChainLayout* lay; uint32_t gen; size_t next_c0 = 0, waits = 0; bool armed = false;   // waits: c0 records 0..waits-1 may have a kernel waiting
+    ChainEnqueuer* helper = nullptr;               // a posted job refers to the caller's frame: it must have returned before the frame goes
+    ~ChainGuard() {
+        if (!armed) return;
+        for (size_t r = next_c0; r < waits; ++r)
+            __atomic_store_n(reinterpret_cast<uint32_t*>(c->h_chain + lay->c0_seq(r)), gen | 0x80000000u, __ATOMIC_RELEASE);
+        if (helper) (void)helper->wait(nullptr);
+        (void)hipStreamSynchronize(c->stream);
+    }
+};
+int32_t ensure_chain(sh_ctx* c, size_t bytes);
+// Wait for a sequence word of the chain to carry `gen` without any HIP call: SH_OK, WAIT_RETRY (a wait kernel gave up), WAIT_ENQUEUE_FAILED
+// (the enqueue thread's job failed) or an error (timeout).
+static const int32_t WAIT_RETRY = 1, WAIT_ENQUEUE_FAILED = 2;
+int32_t wait_seq(sh_ctx* c, const uint32_t* flag, uint32_t gen, uint32_t round, double deadline_s, const ChainEnqueuer* helper);
 int32_t check_params(const sh_fri_params* p, fp* offset);
 uint32_t forest_step(uint32_t lg, size_t B, bool* quad);   // levels the next launch of a forest reduction takes off B trees of 2^lg digests; which kernel
 // What a commit leaves resident on the device for the query phase (one codeword): the codeword of every round and, per

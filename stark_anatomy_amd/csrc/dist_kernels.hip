@@ -22,6 +22,32 @@ __global__ __launch_bounds__(256) void k_transpose16(const uint4* __restrict__ i
         if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][ty + k];
     }
 }
+// The same transpose with the four-step twiddle folded into the read: out[c][r] = in[r][c]·w_n^((row0 + r)·c) — the pack of the
+// exchange between the column and the row transforms, which saves the separate pass over the slice that k_twiddle_scale was.
+__global__ __launch_bounds__(256) void k_transpose16_tw(const fp* __restrict__ in, fp* __restrict__ out, uint32_t rows, uint32_t cols, const fp* __restrict__ tw,
+                                                        uint32_t log_n, uint64_t row0) {
+    __shared__ uint4 tile[32][33];
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const uint32_t c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const uint64_t nmask = ((uint64_t)1 << log_n) - 1;
+#pragma unroll
+    for (uint32_t k = 0; k < 32; k += 8) {
+        const uint32_t r = r0 + ty + k, c = c0 + tx;
+        if (r < rows && c < cols) {
+            const uint64_t e = (((row0 + r) & nmask) * c) & nmask;
+            fp t = tw[e & ((1u << NTT_TW_LO_BITS) - 1)];
+            if (log_n > NTT_TW_LO_BITS) t = mont_mul(t, tw[(1u << NTT_TW_LO_BITS) + (e >> NTT_TW_LO_BITS)]);
+            const fp v = mont_mul(in[(size_t)r * cols + c], t);
+            tile[ty + k][tx] = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < 32; k += 8) {
+        const uint32_t c = c0 + ty + k, r = r0 + tx;
+        if (r < rows && c < cols) reinterpret_cast<uint4*>(out)[(size_t)c * rows + r] = tile[tx][ty + k];
+    }
+}
 // out[c][s][r] = in[s][c][r]: the unpack after an exchange — runs of `a` elements keep their order, the two outer
 // indices (P sources, b columns) swap.
 __global__ __launch_bounds__(256) void k_interleave_blocks(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t P, uint32_t b, uint32_t a) {
@@ -47,6 +73,12 @@ hipError_t launch_transpose16(const fp* in, fp* out, size_t rows, size_t cols, h
     if (rows > 0xffffffffu || cols > 0xffffffffu || (rows + 31) / 32 > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_transpose16, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)), dim3(256), 0, s,
                        reinterpret_cast<const uint4*>(in), reinterpret_cast<uint4*>(out), (uint32_t)rows, (uint32_t)cols);
+    return hipGetLastError();
+}
+hipError_t launch_transpose16_tw(const fp* in, fp* out, size_t rows, size_t cols, const fp* tw, uint32_t log_n, uint64_t row0, hipStream_t s) {
+    if (!rows || !cols) return hipSuccess;
+    if (rows > 0xffffffffu || cols > 0xffffffffu || (rows + 31) / 32 > 65535 || log_n > 32 || (row0 + rows) > ((uint64_t)1 << 32)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_transpose16_tw, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)), dim3(256), 0, s, in, out, (uint32_t)rows, (uint32_t)cols, tw, log_n, row0);
     return hipGetLastError();
 }
 hipError_t launch_interleave_blocks(const fp* in, fp* out, size_t P, size_t b, size_t a, hipStream_t s) {

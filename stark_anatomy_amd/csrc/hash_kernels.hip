@@ -132,13 +132,16 @@ __device__ __forceinline__ fp fold_one(fp x, fp y, fp t_mont) {     // t_mont = 
 
 #define FOLD_PER_THREAD 4
 // `lo`/`hi` are the two halves (separate pointers: a rank of the distributed commit holds a slice of each).
+// c0_dev != null: the fold constant comes from device memory (a wait kernel put it there) instead of `c0_mont`; i_base: global
+// index of lo[0] in the round's codeword (a rank's slice of a sharded commit); d_abort as in kernels.h.
 __global__ __launch_bounds__(256) void k_fri_fold(const fp* __restrict__ lo, const fp* __restrict__ hi, size_t half, fp c0_mont, fp omega_inv,
-                                                  fp* __restrict__ out) {
+                                                  fp* __restrict__ out, const fp* __restrict__ c0_dev, size_t i_base, const uint32_t* __restrict__ d_abort) {
+    if (d_abort && __hip_atomic_load(d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * FOLD_PER_THREAD;
     if (i0 >= half) return;
-    // t = c0 · omega_inv^i0 (Montgomery form), by square-and-multiply; then stepped by omega_inv
-    fp step = fp_to_mont(omega_inv), base = step, t = c0_mont;
-    for (size_t e = i0; e; e >>= 1) {
+    // t = c0 · omega_inv^(i_base + i0) (Montgomery form), by square-and-multiply; then stepped by omega_inv
+    fp step = fp_to_mont(omega_inv), base = step, t = c0_dev ? *c0_dev : c0_mont;
+    for (size_t e = i_base + i0; e; e >>= 1) {
         if (e & 1) t = mont_mul(t, base);
         base = mont_mul(base, base);
     }
@@ -165,7 +168,7 @@ template <int KMAX>
 __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const fp* __restrict__ cw, uint32_t log_half, const fp* __restrict__ c0_arr,
                                                            fp c0_single, const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
                                                            fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out, uint32_t K,
-                                                           const uint32_t* __restrict__ d_abort) {
+                                                           const uint32_t* __restrict__ d_abort, size_t w_base) {
     if (d_abort && __hip_atomic_load(d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const 
     const fp* lo = cw + (b << (log_half + 1)) + w0;
     const fp* hi = lo + half;
     digest64 d = subtree_reduce<KMAX>(K, [&](uint32_t q) {
-        fp t = mont_mul(load_tw(tw_inv, log_n_table, (w0 + q) << tw_shift), c0_mont);
+        fp t = mont_mul(load_tw(tw_inv, log_n_table, (w_base + w0 + q) << tw_shift), c0_mont);
         fp v = fold_one(lo[q], hi[q], t);
         out[j0 + q] = v;
         return b2b_leaf(fp_lo64(v), fp_hi64(v));
@@ -196,7 +199,7 @@ template <int K>
 __global__ __launch_bounds__(256, 2) void k_fold_leaf_subtree_staged(const fp* __restrict__ cw, uint32_t log_half, const fp* __restrict__ c0_arr, fp c0_single,
                                                                      const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
                                                                      fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out,
-                                                                     const uint32_t* __restrict__ d_abort) {
+                                                                     const uint32_t* __restrict__ d_abort, size_t w_base) {
     constexpr uint32_t ROW = (1u << K) + 1, WAVE_ELEMS = 64 * ROW;
     __shared__ fp s_v[4 * WAVE_ELEMS];
     if (d_abort && __hip_atomic_load(d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_leaf_subtree_staged(const fp* _
 #pragma unroll 2
     for (uint32_t t = 0; t < (1u << K); ++t) {
         const uint32_t e = t * 64 + lane;
-        const fp tw = mont_mul(load_tw(tw_inv, log_n_table, (ww0 + e) << tw_shift), c0_mont);
+        const fp tw = mont_mul(load_tw(tw_inv, log_n_table, (w_base + ww0 + e) << tw_shift), c0_mont);
         const fp v = fold_one(lo[e], hi[e], tw);
         out[wj0 + e] = v;
         mine[e + (e >> K)] = v;
@@ -287,14 +290,15 @@ hipError_t launch_merkle_tail(const digest64* in, digest64* root, size_t n_in, h
     hipLaunchKernelGGL(k_merkle_tail, dim3(1), dim3(256), 0, s, in, root, (uint32_t)n_in);
     return hipGetLastError();
 }
-hipError_t launch_fri_fold(const fp* lo, const fp* hi, size_t half, fp c0_mont, fp omega_inv, fp* out, hipStream_t s) {
+hipError_t launch_fri_fold(const fp* lo, const fp* hi, size_t half, fp c0_mont, fp omega_inv, fp* out, hipStream_t s, const fp* c0_dev, size_t i_base,
+                           const uint32_t* d_abort) {
     if (!half) return hipErrorInvalidValue;
     const size_t threads = (half + FOLD_PER_THREAD - 1) / FOLD_PER_THREAD;
-    hipLaunchKernelGGL(k_fri_fold, dim3(grid_for(threads, 256)), dim3(256), 0, s, lo, hi, half, c0_mont, omega_inv, out);
+    hipLaunchKernelGGL(k_fri_fold, dim3(grid_for(threads, 256)), dim3(256), 0, s, lo, hi, half, c0_mont, omega_inv, out, c0_dev, i_base, d_abort);
     return hipGetLastError();
 }
 hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* c0_arr, fp c0_single, const fp* tw_inv, uint32_t log_n_table,
-                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s, const uint32_t* d_abort) {
+                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s, const uint32_t* d_abort, size_t w_base) {
     const size_t half = L / 2;
     if (!half || (half & (half - 1)) || !B || K > SUBTREE_KMAX || (half >> K) == 0) return hipErrorInvalidValue;
     uint32_t log_half = 0;
@@ -303,14 +307,14 @@ hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* 
     static const bool no_stage = getenv("STARK_NO_STAGE") != nullptr;
     if (K >= 1 && K <= 3 && (n_out & 255) == 0 && log_half >= 6 + K && !no_stage) {          // whole 256-lane workgroups, waves inside one codeword
         const dim3 grid((unsigned)(n_out >> 8));
-        if (K == 3) hipLaunchKernelGGL(k_fold_leaf_subtree_staged<3>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort);
-        else if (K == 2) hipLaunchKernelGGL(k_fold_leaf_subtree_staged<2>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort);
-        else hipLaunchKernelGGL(k_fold_leaf_subtree_staged<1>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort);
+        if (K == 3) hipLaunchKernelGGL(k_fold_leaf_subtree_staged<3>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort, w_base);
+        else if (K == 2) hipLaunchKernelGGL(k_fold_leaf_subtree_staged<2>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort, w_base);
+        else hipLaunchKernelGGL(k_fold_leaf_subtree_staged<1>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort, w_base);
         return hipGetLastError();
     }
     if (K <= 3) hipLaunchKernelGGL(k_fold_leaf_subtree<3>, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
-                                   log_n_table, tw_shift, out, digests, n_out, K, d_abort);
+                                   log_n_table, tw_shift, out, digests, n_out, K, d_abort, w_base);
     else hipLaunchKernelGGL(k_fold_leaf_subtree<4>, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
-                            log_n_table, tw_shift, out, digests, n_out, K, d_abort);
+                            log_n_table, tw_shift, out, digests, n_out, K, d_abort, w_base);
     return hipGetLastError();
 }

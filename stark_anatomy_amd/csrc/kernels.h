@@ -20,6 +20,8 @@ hipError_t launch_fp_batch_inv_finish(int op, const fp* a, const fp* b, fp* out,
 // ---- dist_kernels.hip (multi-GPU data movement) ----
 // out[c][r] = in[r][c], rows x cols elements (the pack of an all-to-all exchange when cols = P·b)
 hipError_t launch_transpose16(const fp* in, fp* out, size_t rows, size_t cols, hipStream_t s);
+// out[c][r] = in[r][c]·w_n^((row0 + r)·c): the pack with the four-step twiddle folded in (tw: the two-level table of get_twiddles)
+hipError_t launch_transpose16_tw(const fp* in, fp* out, size_t rows, size_t cols, const fp* tw, uint32_t log_n, uint64_t row0, hipStream_t s);
 // out[c][s][r] = in[s][c][r], (P, b, a) -> (b, P, a): the unpack after the exchange
 hipError_t launch_interleave_blocks(const fp* in, fp* out, size_t P, size_t b, size_t a, hipStream_t s);
 // leaves[i] = pairs[i][0], leaves[P + i] = pairs[i][1]
@@ -102,13 +104,18 @@ hipError_t launch_quad_reduce(const digest64* in, digest64* out, size_t n_in, ui
 
 // ---- hash_kernels.hip (FRI round) ----
 // generic split-and-fold (any omega): out[i] = (a+b)/2 + c0·omega^-i·(a-b),  c0 = alpha/(2·offset)
-hipError_t launch_fri_fold(const fp* lo, const fp* hi, size_t half, fp c0_mont, fp omega_inv, fp* out, hipStream_t s);
+// c0_dev != null: the constant is read from device memory instead (a wait kernel put it there); i_base: global index of lo[0] in the
+// round's codeword (a rank's slice of a sharded commit)
+hipError_t launch_fri_fold(const fp* lo, const fp* hi, size_t half, fp c0_mont, fp omega_inv, fp* out, hipStream_t s, const fp* c0_dev = nullptr, size_t i_base = 0,
+                           const uint32_t* d_abort = nullptr);
 // fused round for B codewords of length L stored back to back: fold each into length L/2 (also back to back in
 // `out`) with twiddles w_N^-(i << tw_shift) from the inverse table of the top-level domain, and emit the 2^K-leaf
 // subtree digests of the folded codewords.  c0 = alpha/(2*offset) in Montgomery form: per codeword from the device
 // array `c0_arr`, or `c0_single` when c0_arr is null.
 hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* c0_arr, fp c0_single, const fp* tw_inv, uint32_t log_n_table,
-                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s, const uint32_t* d_abort = nullptr);
+                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s, const uint32_t* d_abort = nullptr, size_t w_base = 0);
+// w_base: global index of output 0 in the round's folded codeword (B == 1; a rank's slice of a sharded commit, whose lo | hi halves sit
+// back to back in `cw`): the twiddle of output w is w_N^-((w_base + w) << tw_shift)
 
 // ---- round_kernels.hip (the commit's serial chain) ----
 // one workgroup: wait until the pinned host word *h_seq carries `gen` (bit 31 = abort), then copy the B fold constants

@@ -195,6 +195,158 @@ class GpuEngine:
         return sample(ps.prover_fiat_shamir()).value()
 
 
+# ------------------------------------------------------------------------------------------------ native path (sh_dist_*)
+class NativeDist:
+    """The C++ orchestration of csrc/api_dist.hip for one process group: sh_dist_ntt / sh_dist_coset_lde / sh_dist_fri_commit.
+    Over "nccl" the library talks to RCCL itself (rank 0's unique id travels through torch.distributed once); over any other
+    backend (gloo rehearsals, several ranks on one card) the three transport operations are Python callbacks that stage the
+    device buffers through host memory and the torch collective — the orchestration in C++ is the same code either way."""
+
+    def __init__(self, engine, group=None, force_callbacks=False):
+        import torch
+        from . import _lib
+        self.engine, self.group, self._lib = engine, group, _lib
+        self.P, self.g = _world_rank(group)
+        self.handle = _lib.dist_t()
+        ctx = engine.ctx
+        dist = _dist()
+        use_rccl = (self.P == 1 or dist.get_backend(group) == "nccl") and not force_callbacks
+        if use_rccl:
+            uid = np.zeros(128, dtype=np.uint8)
+            if self.g == 0:
+                _lib.check(_lib.lib.sh_dist_unique_id(uid.ctypes.data_as(_lib.u8p)))
+            if self.P > 1:
+                t = torch.from_numpy(uid).to(engine.device)
+                dist.broadcast(t, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+                uid = t.cpu().numpy()
+            _lib.check(_lib.lib.sh_dist_create(ctx.handle, self.g, self.P, uid.ctypes.data_as(_lib.u8p), C.byref(self.handle)))
+            self.transport = "rccl"
+        else:
+            self._cbs = (_lib.ALL_TO_ALL_CB(self._cb_all_to_all), _lib.ALL_GATHER_CB(self._cb_all_gather), _lib.SENDRECV_CB(self._cb_sendrecv))
+            self._tr = _lib.DistTransport(None, *self._cbs)
+            _lib.check(_lib.lib.sh_dist_create_with_transport(ctx.handle, self.g, self.P, C.byref(self._tr), C.byref(self.handle)))
+            self.transport = "callbacks"
+        self.errors = []
+
+    # -- host-staged transport (the library calls these from its enqueue thread or from the calling thread)
+    def _down(self, ptr, nbytes):
+        a = np.empty(nbytes, dtype=np.uint8)
+        self._lib.check(self._lib.lib.sh_dev_download(self.engine.ctx.handle, a.ctypes.data, ptr, nbytes))
+        return a
+
+    def _up(self, ptr, a):
+        a = np.ascontiguousarray(a)
+        self._lib.check(self._lib.lib.sh_dev_upload(self.engine.ctx.handle, ptr, a.ctypes.data, a.nbytes))
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except Exception as e:  # never unwind through the C frame
+            self.errors.append(e)
+            return 1
+
+    def _cb_all_to_all(self, _user, d_send, d_recv, nbytes, _stream):
+        def run():
+            import torch
+            s = torch.from_numpy(self._down(d_send, nbytes * self.P))
+            r = torch.empty_like(s)
+            _dist().all_to_all_single(r, s, group=self.group)
+            self._up(d_recv, r.numpy())
+        return self._guard(run)
+
+    def _cb_all_gather(self, _user, d_send, d_recv, nbytes, _stream):
+        def run():
+            import torch
+            s = torch.from_numpy(self._down(d_send, nbytes))
+            r = torch.empty(nbytes * self.P, dtype=torch.uint8)
+            _dist().all_gather_into_tensor(r, s, group=self.group)
+            self._up(d_recv, r.numpy())
+        return self._guard(run)
+
+    def _cb_sendrecv(self, _user, ops, n_ops, _stream):
+        def run():
+            import torch
+            dist = _dist()
+            gr = (lambda r: r) if self.group is None else (lambda r: dist.get_global_rank(self.group, r))
+            p2p, landed = [], []
+            for i in range(n_ops):
+                op = ops[i]
+                if op.is_send:
+                    buf = torch.from_numpy(self._down(op.d_buf, op.bytes))
+                    landed.append((None, buf))
+                    p2p.append(dist.P2POp(dist.isend, buf, gr(op.peer), group=self.group))
+                else:
+                    buf = torch.empty(op.bytes, dtype=torch.uint8)
+                    landed.append((op.d_buf, buf))
+                    p2p.append(dist.P2POp(dist.irecv, buf, gr(op.peer), group=self.group))
+            if p2p:
+                for w in dist.batch_isend_irecv(p2p):
+                    w.wait()
+            for ptr, buf in landed:
+                if ptr is not None:
+                    self._up(ptr, buf.numpy())
+        return self._guard(run)
+
+    def _check(self, rc):
+        if self.errors:
+            e = self.errors[:]
+            self.errors.clear()
+            raise e[0]
+        self._lib.check(rc)
+
+    def selftest(self):
+        self._check(self._lib.lib.sh_dist_selftest(self.handle))
+
+    def ntt(self, local, log_n, inverse=False, input_layout="natural", output_layout="natural"):
+        with self.engine.scope():
+            out = self.engine.torch.empty_like(local.reshape(-1, 2))
+        self._check(self._lib.lib.sh_dist_ntt(self.handle, local.data_ptr(), log_n, int(bool(inverse)), int(input_layout == "columns"),
+                                              int(output_layout == "rows"), out.data_ptr()))
+        return out
+
+    def coset_lde(self, local_coeffs, log_n, log_expansion, offset):
+        from .context import _u64p, scalar
+        m_out = (local_coeffs.numel() // 2) << log_expansion
+        with self.engine.scope():
+            out = self.engine.torch.empty((m_out, 2), dtype=local_coeffs.dtype, device=local_coeffs.device)
+        off = scalar(int(offset.value() if hasattr(offset, "value") else offset))
+        self._check(self._lib.lib.sh_dist_coset_lde(self.handle, local_coeffs.data_ptr(), log_n, log_expansion, _u64p(off), out.data_ptr()))
+        return out
+
+    def fri_commit(self, local, N, offset, expansion_factor=4, num_colinearity_tests=17, proof_stream=None, min_half=1 << 16):
+        from .context import _u8p, _u64p
+        _lib = self._lib
+        ps = proof_stream if proof_stream is not None else self.engine.new_proof_stream()
+        R = int(_lib.lib.sh_fri_num_rounds(N, expansion_factor, num_colinearity_tests))
+        roots = np.zeros((max(R, 1), 64), dtype=np.uint8)
+        last = np.empty((N >> max(R - 1, 0), 2), dtype=np.uint64)
+        last_len = C.c_size_t(0)
+        p = _lib.FriParams()
+        off = int(offset.value() if hasattr(offset, "value") else offset)
+        p.expansion, p.num_colinearity_tests = expansion_factor, num_colinearity_tests
+        p.offset[0], p.offset[1] = off & _MASK, off >> 64
+        self._check(_lib.lib.sh_dist_fri_commit(self.handle, local.data_ptr(), N, C.byref(p), ps.handle, min_half, _u8p(roots), _u64p(last),
+                                                C.byref(last_len)))
+        return [roots[i].tobytes() for i in range(R)], last[:last_len.value], ps
+
+    def close(self):
+        if self.handle:
+            self._lib.lib.sh_dist_destroy(self.handle)
+            self.handle = None
+
+
+def _native(engine, group):
+    """the engine's NativeDist for this group, or None (CPU rehearsal engines, STARK_DIST_PYTHON=1: the Python orchestration below)"""
+    if not hasattr(engine, "ctx") or os.environ.get("STARK_DIST_PYTHON") == "1":
+        return None
+    cache = engine.__dict__.setdefault("_native_dist", {})
+    key = id(group)
+    if key not in cache:
+        cache[key] = NativeDist(engine, group, force_callbacks=os.environ.get("STARK_DIST_CALLBACKS") == "1")
+    return cache[key]
+
+
 # ------------------------------------------------------------------------------------------------ exchanges
 def _all_to_all(send, group):
     """send: (P, ...) contiguous; block s goes to rank s; returns (P, ...) with block s received from rank s."""
@@ -308,6 +460,11 @@ def dist_ntt(local, log_n, engine, group=None, inverse=False, input_layout="natu
     input_layout  "natural": local = x[g·n/P : (g+1)·n/P];  "columns": local[c][j1] = x[j1·n2 + g·n2/P + c].
     output_layout "natural": returns X[g·n/P : (g+1)·n/P];  "rows":    returns [k1l][k2] = X[g·n1/P + k1l + n1·k2]."""
     P, g = _world_rank(group)
+    nat = _native(engine, group)
+    if nat is not None:
+        if local.numel() != 2 * ((1 << log_n) // P):
+            raise ValueError("local slice has the wrong length")
+        return nat.ntt(local.contiguous(), log_n, inverse, input_layout, output_layout)
     l1, l2 = split_log(log_n)
     n1, n2 = 1 << l1, 1 << l2
     if n1 % P or n2 % P:
@@ -342,6 +499,9 @@ def dist_coset_lde(local_coeffs, log_n, log_expansion, offset, engine, group=Non
     m_in, m_out = n // P, N // P
     if local_coeffs.numel() != 2 * m_in:
         raise ValueError("local coefficient slice has the wrong length")
+    nat = _native(engine, group)
+    if nat is not None:
+        return nat.coset_lde(local_coeffs.contiguous(), log_n, log_expansion, offset)
     with engine.scope():
         scaled = engine.scale_powers(local_coeffs.reshape(-1, 2).clone(), g * m_in, offset)
         # padded vector = [coeffs | zeros]; rank g owns padded[g·m_out, (g+1)·m_out), m_out = 2^e·m_in: the coefficient slice
@@ -402,6 +562,9 @@ def dist_fri_commit(local, N, engine, offset, expansion_factor=4, num_colinearit
         raise ValueError("codeword does not split over the ranks")
     if local.numel() != 2 * (N // P):
         raise ValueError("local slice has the wrong length")
+    nat = _native(engine, group)
+    if nat is not None:
+        return nat.fri_commit(local.contiguous(), N, offset, expansion_factor, num_colinearity_tests, proof_stream, max(1, min_half))
     ps = proof_stream if proof_stream is not None else engine.new_proof_stream()
     offset = int(offset.value() if hasattr(offset, "value") else offset)
     L, chunk, roots = N, local.reshape(-1, 2), []

@@ -129,11 +129,30 @@ def test_pair_roots_stay_on_device(ctx):
     d_cw.free(); d_pairs.free()
 
 
-@pytest.mark.parametrize("log_n", [2, 9, 16, 20, 24])
-def test_four_step_single_rank(engine, log_n):
-    """P = 1: the four-step decomposition (batched column NTTs, twiddle, batched row NTTs, transposes by k_transpose16)
-    equals the direct transform; from 2^20 against the library's own one-shot NTT, below that against the oracle."""
+def test_native_dist_rccl_single_rank(engine):
+    """sh_dist_create on one rank: librccl is dlopen()ed, a one-rank communicator is made, and sh_dist_selftest drives all three
+    transport operations (grouped ncclSend/ncclRecv as all-to-all and as a point-to-point pair, ncclAllGather) on the card."""
     from stark_anatomy_amd import dist_ntt as dn
+    nat = dn.NativeDist(engine)
+    assert nat.transport == "rccl" and (nat.P, nat.g) == (1, 0)
+    nat.selftest()
+    nat.close()
+
+
+@pytest.mark.parametrize("mode", ["native-direct", "native-four-step", "python"])
+@pytest.mark.parametrize("log_n", [2, 9, 16, 20, 24])
+def test_four_step_single_rank(engine, log_n, mode, monkeypatch):
+    """P = 1: the four-step decomposition (batched column NTTs, twiddle, batched row NTTs, transposes by k_transpose16)
+    equals the direct transform; from 2^20 against the library's own one-shot NTT, below that against the oracle.
+    native-*: sh_dist_ntt (one rank takes the direct transform unless the four-step code is forced); python: dist_ntt.py's own
+    orchestration over the same kernels (what the gloo rehearsals with a CPU engine run)."""
+    from stark_anatomy_amd import dist_ntt as dn
+    if mode == "native-four-step":
+        monkeypatch.setenv("STARK_HIP_DIST_FORCE_FOURSTEP", "1")
+    if mode == "python":
+        if log_n == 24:
+            pytest.skip("covered by the native path at this size")
+        monkeypatch.setenv("STARK_DIST_PYTHON", "1")
     n = 1 << log_n
     x = co.splitmix_elems(31 + log_n, n)
     X = engine.to_host(dn.dist_ntt(engine.from_host(x), log_n, engine))
@@ -143,8 +162,46 @@ def test_four_step_single_rank(engine, log_n):
     assert np.array_equal(back, x)
 
 
-def test_dist_lde_and_commit_single_rank(engine):
+@pytest.mark.parametrize("layouts", [("columns", "natural"), ("natural", "rows"), ("columns", "rows")])
+def test_four_step_layouts_single_rank(engine, layouts, monkeypatch):
+    """sh_dist_ntt's relaxed layouts (one exchange instead of three) against the natural-order transform, P = 1."""
     from stark_anatomy_amd import dist_ntt as dn
+    monkeypatch.setenv("STARK_HIP_DIST_FORCE_FOURSTEP", "1")
+    log_n = 13
+    l1, l2 = dn.split_log(log_n)
+    n1, n2 = 1 << l1, 1 << l2
+    x = co.splitmix_elems(71, 1 << log_n)
+    exp = co.ntt(x)
+    inp = x if layouts[0] == "natural" else np.ascontiguousarray(x.reshape(n1, n2, 2).transpose(1, 0, 2)).reshape(-1, 2)     # [j2][j1]
+    got = engine.to_host(dn.dist_ntt(engine.from_host(inp), log_n, engine, input_layout=layouts[0], output_layout=layouts[1]))
+    want = exp if layouts[1] == "natural" else np.ascontiguousarray(exp.reshape(n2, n1, 2).transpose(1, 0, 2)).reshape(-1, 2)  # [k1][k2]
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("log_N,min_half", [(16, 1 << 8), (16, 1), (20, 1 << 16), (22, 1 << 16), (22, 1 << 10)])
+def test_native_sharded_commit_single_rank(engine, log_N, min_half):
+    """sh_dist_fri_commit on one rank == the single-GPU commit (oracle-checked at these sizes), byte for byte: the sharded rounds
+    (fused fold + leaf subtree with a slice offset, chain records, enqueue thread) followed by the locally committed tail."""
+    from stark_anatomy_amd import dist_ntt as dn
+    N = 1 << log_N
+    cw = co.splitmix_elems(900 + log_N, N)
+    roots, last, ps = dn.dist_fri_commit(engine.from_host(cw), N, engine, G, 4, 17, min_half=min_half)
+    if log_N <= 16:
+        r, _, l, ops = co.fri_commit(cw, 4, 17, G)
+        ser = ops.serialize()
+    else:
+        ps1 = sa.ProofStream()
+        roots1, l = sa.Fri(G, None, N, 4, 17, ctx=engine.ctx).commit(cw, ps1)
+        r, ser = [h.as_bytes() for h in roots1], ps1.serialize()
+    assert [bytes(a) for a in roots] == r and np.array_equal(last, l) and ps.serialize() == ser
+    assert engine.ctx.chain_retries == 0
+
+
+@pytest.mark.parametrize("mode", ["native", "python"])
+def test_dist_lde_and_commit_single_rank(engine, mode, monkeypatch):
+    from stark_anatomy_amd import dist_ntt as dn
+    if mode == "python":
+        monkeypatch.setenv("STARK_DIST_PYTHON", "1")
     log_n = 14
     c = co.splitmix_elems(5, 1 << log_n)
     cw = dn.dist_coset_lde(engine.from_host(c), log_n, 2, G, engine)
@@ -171,6 +228,10 @@ log_n = int(os.environ["TEST_LOG_N"]); n = 1 << log_n
 x = np.load(os.environ["TEST_IN"])
 sl = lambda a, m: a[g * (m // P):(g + 1) * (m // P)]
 res = {}
+nat = dn._native(eng, None)
+if nat is not None:
+    assert nat.transport == "callbacks"
+    nat.selftest()
 X = dn.dist_ntt(eng.from_host(sl(x, n)), log_n, eng)
 res["ntt"] = eng.to_host(X)
 m = n // 4
@@ -186,10 +247,13 @@ if g == 0:
 '''
 
 
-@pytest.mark.parametrize("log_n", [14, 22])
-def test_two_ranks_one_gpu_gloo(tmp_path, log_n):
+@pytest.mark.parametrize("log_n,mode", [(14, "native"), (14, "python"), (22, "native")])
+def test_two_ranks_one_gpu_gloo(tmp_path, log_n, mode):
     """14: against the oracle.  22 (config 5's shape at a size two ranks on one card finish in seconds): against the
-    single-GPU NTT / LDE / commit of the product, which are themselves oracle-checked at that size."""
+    single-GPU NTT / LDE / commit of the product, which are themselves oracle-checked at that size.
+    native: the C++ orchestration (sh_dist_*) with its transport operations served by gloo-backed callbacks that stage through
+    host memory — every exchange, regroup and sub-root gather of the product code with two real ranks; python: dist_ntt.py's
+    own orchestration over the same kernels."""
     n = 1 << log_n
     x = co.splitmix_elems(99, n)
     np.save(tmp_path / "in.npy", x)
@@ -198,6 +262,8 @@ def test_two_ranks_one_gpu_gloo(tmp_path, log_n):
     out = tmp_path / "out.pkl"
     env = dict(os.environ, REPO_ROOT=ROOT, TEST_LOG_N=str(log_n), TEST_IN=str(tmp_path / "in.npy"), TEST_OUT=str(out),
                PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+    if mode == "python":
+        env["STARK_DIST_PYTHON"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29731", str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
