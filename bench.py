@@ -273,6 +273,25 @@ def main():
         extra[f"fri_commit_2^{other}_ms"] = 1e3 * dt_o / so
         d_o.free()
 
+        # ---- the literal drop-in call: codeword in pageable HOST memory (PCIe-inclusive; never `value`) ----
+        for lh in (24, 20):
+            if lh > log_n:
+                continue
+            nh = 1 << lh
+            raw_h = random_elems(nh, 7000 + lh + rank).copy()
+            raw_h[:, 1] &= np.uint64(0x7FFFFFFFFFFFFFFF)                 # canonical (< p) without a device pass
+            Rh = int(_lib.lib.sh_fri_num_rounds(nh, 4, 17))
+            roots_h = np.zeros((Rh, 64), dtype=np.uint8)
+            last_h = np.empty((nh >> (Rh - 1), 2), dtype=np.uint64)
+
+            def host_commit():
+                ll = C.c_size_t(0)
+                ps = sa.ProofStream()
+                _lib.check(_lib.lib.sh_fri_commit_proofstream(H, _u64p(raw_h), nh, C.byref(params), ps.handle, _u8p(roots_h), _u64p(last_h), C.byref(ll)))
+            dt_h = timed(host_commit, 4, 2)
+            extra[f"fri_commit_host_2^{lh}_ms"] = 1e3 * dt_h / 4
+            del raw_h
+
         # ---- config 1 widened: full prove (commit + query phase) and host verify at 2^20, on a low-degree codeword ----
         lp = 20
         d_pc = resident_codeword(1 << (lp - 2), 4000 + rank)

@@ -148,6 +148,10 @@ int32_t sh_ctx_destroy(sh_ctx* c) {
     if (c->h_mail) (void)hipHostFree(c->h_mail);
     if (c->h_batch) (void)hipHostFree(c->h_batch);
     if (c->h_chain) (void)hipHostFree(c->h_chain);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (auto& e : c->stage_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& st : c->copy_stream) if (st) (void)hipStreamDestroy(st);
+    if (c->ev_upload0) (void)hipEventDestroy(c->ev_upload0);
     if (c->h_query) (void)hipHostFree(c->h_query);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -134,8 +134,10 @@ typedef std::function<int32_t(uint32_t r, const uint8_t* roots, bool want, fp* a
 // `keep`: when set (B == 1), every round's codeword stays resident (round r >= 1 at offset N - N/2^(r-1) of one N-element
 // arena, instead of the two ping-pong buffers), and so does every digest array that the round's kernels write on the way up
 // its tree (SCR_LEVELS instead of the two ping-pong digest buffers) — the query phase opens paths from them afterwards.
+// `r0_leaves_hashed`: the subtree digests of round 0 already sit in SCR_DIG_A (the host-buffer entry points hash every chunk of the
+// codeword as it lands): the first enqueue of round 0 skips its leaf kernel (a re-enqueue after an abandoned round does not).
 static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, const sh_fri_params* prm, const RoundFn& fn,
-                               uint64_t* last_out, size_t* last_len, CommitKeep* keep) {
+                               uint64_t* last_out, size_t* last_len, CommitKeep* keep, bool r0_leaves_hashed = false) {
     const uint32_t log_N = ilog2(N);
     fp off;
     SHCHK(check_params(prm, &off));
@@ -275,7 +277,8 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
             else {
                 const uint32_t K = sh.K;
                 digest64* dst = first ? first : c->d_root;              // a tree that ends in its lanes (N <= 2^K): one digest, the root
-                HIPCHK(launch_leaf_subtree(d_cws, dst, (B * N) >> K, K, c->stream));
+                if (r0_leaves_hashed && !keep) r0_leaves_hashed = false;                  // consumed: dst == SCR_DIG_A holds them
+                else HIPCHK(launch_leaf_subtree(d_cws, dst, (B * N) >> K, K, c->stream));
                 SHCHK(enqueue_forest_reduce(c, dst, other, dst, log_N - K, B, rec, gen, d_abort, st, K, d_roots));
             }
         } else {
@@ -421,8 +424,87 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
     return SH_OK;
 }
 
+// ------------------------------------------------------------------ host buffer -> device, pipelined
+// A pageable host buffer reaches the device through the runtime's own staging at ~29 GB/s (2^24 elements: 9.3 ms) and nothing
+// overlaps it; the caller's buffer cannot be pinned in place (hipHostRegister is refused for an ordinary user on the box).  So:
+// a ring of pinned slots per context; the context's worker threads copy chunk i+1 of the caller's buffer into a slot (memcpy
+// split over the threads) while the copy engine moves chunk i from its slot; `after_chunk` puts kernels behind a chunk's copy.
+#define STAGE_SLOTS 4
+#define STAGE_SLOT_BYTES ((size_t)8 << 20)
+int32_t upload_pipelined(sh_ctx* c, const uint64_t* host, size_t n_elems, fp* d_dst, const std::function<int32_t(size_t, size_t)>& after_chunk) {
+    const size_t bytes = n_elems * sizeof(fp);
+    static const bool plain = getenv("STARK_HIP_PLAIN_UPLOAD") != nullptr;
+    if (plain || bytes < ((size_t)1 << 20)) {                            // small: one copy
+        HIPCHK(hipMemcpyAsync(d_dst, host, bytes, hipMemcpyHostToDevice, c->stream));
+        return after_chunk ? after_chunk(0, n_elems) : SH_OK;
+    }
+    if (!c->h_stage) {
+        HIPCHK(hipHostMalloc((void**)&c->h_stage, STAGE_SLOTS * STAGE_SLOT_BYTES, hipHostMallocDefault));
+        for (int i = 0; i < STAGE_SLOTS; ++i) HIPCHK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_upload0, hipEventDisableTiming));
+    }
+    // The copies run on a stream of their own; the context's stream waits for a chunk's event before the work on that chunk, so
+    // chunk i's kernels run beside chunk i+1's copy.  Measured at 2^24 / 2^20 (commit from pageable memory, ms): copies on the
+    // context's stream 10.2 / 1.26, one copy stream 8.2 / 1.20, two alternating 9.1 / 2.0 (STARK_HIP_UPLOAD_STREAMS=0|1|2).
+    static const unsigned n_copy_streams = [] { const char* e = getenv("STARK_HIP_UPLOAD_STREAMS"); const int v = e ? atoi(e) : 0; return (unsigned)(v >= 0 && v <= 2 && e ? v : 1); }();
+    if (n_copy_streams) {
+        HIPCHK(hipEventRecord(c->ev_upload0, c->stream));                   // the destination may still be read by work enqueued before
+        for (unsigned i = 0; i < n_copy_streams; ++i) HIPCHK(hipStreamWaitEvent(c->copy_stream[i], c->ev_upload0, 0));
+    }
+    if (!c->pool) {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (hw > 8) hw = 8;
+        try { c->pool = new SpinPool(hw > 1 ? hw - 1 : 0); } catch (const std::system_error&) { c->pool = new SpinPool(0); }
+    }
+    static const unsigned copy_threads = [] { const char* e = getenv("STARK_HIP_UPLOAD_THREADS"); const int v = e ? atoi(e) : 0; return (unsigned)(v >= 1 && v <= 8 ? v : 6); }();
+    c->pool->wake(copy_threads);
+    struct Parker { SpinPool* p; ~Parker() { p->park(); } } parker{c->pool};
+    const size_t chunk_bytes = bytes < 4 * STAGE_SLOT_BYTES ? ((bytes / 4 + 4095) & ~(size_t)4095) : STAGE_SLOT_BYTES;   // a short buffer still pipelines
+    const size_t chunk_elems = chunk_bytes / sizeof(fp);
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(host);
+    size_t slot = 0, used = 0;
+    for (size_t e0 = 0; e0 < n_elems; e0 += chunk_elems, slot = (slot + 1) % STAGE_SLOTS, ++used) {
+        const size_t ne = n_elems - e0 < chunk_elems ? n_elems - e0 : chunk_elems, nb = ne * sizeof(fp);
+        uint8_t* stage = c->h_stage + slot * STAGE_SLOT_BYTES;
+        if (used >= STAGE_SLOTS) HIPCHK(hipEventSynchronize(c->stage_ev[slot]));          // the copy that last used this slot has left it
+        const uint8_t* from = src + e0 * sizeof(fp);
+        c->pool->parallel((nb + 4095) >> 12, [&](size_t p0, size_t p1) {                  // 4 KiB pages, one contiguous slice per thread
+            const size_t b0 = p0 << 12, b1 = (p1 << 12) < nb ? (p1 << 12) : nb;
+            if (b0 < b1) memcpy(stage + b0, from + b0, b1 - b0);
+        });
+        hipStream_t cs = n_copy_streams ? c->copy_stream[used % n_copy_streams] : c->stream;
+        HIPCHK(hipMemcpyAsync(d_dst + e0, stage, nb, hipMemcpyHostToDevice, cs));
+        HIPCHK(hipEventRecord(c->stage_ev[slot], cs));
+        if (n_copy_streams) HIPCHK(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
+        if (after_chunk) SHCHK(after_chunk(e0, ne));
+    }
+    return SH_OK;
+}
+// Upload of ONE codeword for a commit, with round 0's leaf hashing started on every chunk as it lands (the subtree digests of a
+// chunk are independent of the rest).  *hashed tells the driver that SCR_DIG_A already holds round 0's digests.
+static int32_t upload_codeword_hashing(sh_ctx* c, const uint64_t* host, size_t N, fp* d_dst, bool* hashed) {
+    *hashed = false;
+    const uint32_t lg = ilog2(N);
+    uint32_t K = leaf_subtree_k(lg);
+    if (K > lg) K = lg;
+    static const bool use_round_wg = getenv("STARK_NO_ROUND_WG") == nullptr;
+    const bool small = use_round_wg && N <= ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL) && lg >= 1;      // the fused one-launch round hashes its own leaves
+    void* dig = nullptr;
+    const bool can = !small && K < lg && (N * sizeof(fp)) >= ((size_t)1 << 20);
+    if (can) SHCHK(ensure_scratch(c, SCR_DIG_A, (N >> K) * sizeof(digest64), &dig));
+    SHCHK(upload_pipelined(c, host, N, d_dst, [&](size_t e0, size_t ne) -> int32_t {
+        if (!can) return SH_OK;
+        if ((e0 | ne) & (((size_t)256 << K) - 1)) return sh_fail(SH_EHIP, "upload: chunk not aligned to whole workgroups of subtrees");   // sizes are powers of two: cannot happen
+        HIPCHK(launch_leaf_subtree(d_dst + e0, (digest64*)dig + (e0 >> K), ne >> K, K, c->stream));
+        return SH_OK;
+    }));
+    *hashed = can;
+    return SH_OK;
+}
+
 int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_params* prm, sh_transcript_cb cb, void* user,
-                       uint8_t* roots_out, uint64_t* last_out, size_t* last_len, CommitKeep* keep) {
+                       uint8_t* roots_out, uint64_t* last_out, size_t* last_len, CommitKeep* keep, bool r0_leaves_hashed) {
     CTXCHK(c);
     if (!d_cw || !cb || !roots_out || !last_out || !last_len) return sh_fail(SH_EINVAL, "fri_commit: null pointer");
     if (!is_pow2(N)) return sh_fail(SH_EINVAL, "fri_commit: N must be a power of two");
@@ -435,7 +517,7 @@ int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_params*
             if (want) alpha_out[0] = fp_load_host(alpha_w);
             return SH_OK;
         };
-        return fri_commit_core(c, d_cw, 1, N, prm, fn, last_out, last_len, keep);
+        return fri_commit_core(c, d_cw, 1, N, prm, fn, last_out, last_len, keep, r0_leaves_hashed);
     } catch (const std::bad_alloc&) { return sh_fail(SH_ENOMEM, "fri_commit: out of host memory");
     } catch (...) { return sh_fail(SH_ENOMEM, "fri_commit: unexpected exception on the host side"); }
 }
@@ -630,8 +712,9 @@ int32_t sh_fri_commit(sh_ctx* c, const uint64_t* codeword, size_t N, const sh_fr
     if (!is_pow2(N) || ilog2(N) > SH_MAX_LOG_N) return sh_fail(SH_EINVAL, "sh_fri_commit: N must be a power of two <= 2^28");
     void* d;
     SHCHK(ensure_scratch(c, SCR_IO_C, N * 16, &d));
-    HIPCHK(hipMemcpyAsync(d, codeword, N * 16, hipMemcpyHostToDevice, c->stream));
-    return fri_commit_dev(c, (const fp*)d, N, params, cb, user, roots_out, last_codeword_out, last_len);
+    bool hashed = false;
+    SHCHK(upload_codeword_hashing(c, codeword, N, (fp*)d, &hashed));
+    return fri_commit_dev(c, (const fp*)d, N, params, cb, user, roots_out, last_codeword_out, last_len, nullptr, hashed);
 }
 int32_t sh_dev_fri_commit_proofstream(sh_ctx* c, const uint64_t* d_codeword, size_t N, const sh_fri_params* params, sh_proofstream* ps,
                                       uint8_t* roots_out, uint64_t* last_codeword_out, size_t* last_len) {
@@ -659,7 +742,7 @@ int32_t sh_fri_commit_batch(sh_ctx* c, const uint64_t* codewords, size_t B, size
     if (B == 0 || !is_pow2(N) || ilog2(N) > SH_MAX_LOG_N || ilog2(B) + ilog2(N) > 30) return sh_fail(SH_EINVAL, "sh_fri_commit_batch: bad batch shape");
     void* d;
     SHCHK(ensure_scratch(c, SCR_IO_C, B * N * 16, &d));
-    HIPCHK(hipMemcpyAsync(d, codewords, B * N * 16, hipMemcpyHostToDevice, c->stream));
+    SHCHK(upload_pipelined(c, codewords, B * N, (fp*)d, nullptr));
     return fri_commit_batch_dev(c, (const fp*)d, B, N, params, streams, roots_out, last_codewords_out, last_len);
 }
 

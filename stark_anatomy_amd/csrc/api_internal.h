@@ -201,6 +201,10 @@ struct sh_ctx {
     uint8_t* d_chain = nullptr;                  // device view of h_chain
     size_t chain_bytes = 0;
     SpinPool* pool = nullptr;                    // transcript workers of batched commits (asleep between calls)
+    uint8_t* h_stage = nullptr;                  // pinned staging ring of the host-buffer entry points (upload_pipelined, api_fri.hip)
+    hipEvent_t stage_ev[8] = {};                 // slot i may be refilled once its last copy has left it
+    hipStream_t copy_stream[2] = {};             // the copies alternate between two streams of their own (two copy engines)
+    hipEvent_t ev_upload0 = nullptr;             // orders the copy streams after what the context's stream held before the upload
     ChainEnqueuer* enqueuer = nullptr;           // makes the HIP calls of a commit's rounds while the caller serves the chain
     sh_ctx* sub = nullptr;                       // second stream + buffers for the second lock-step group of a batched commit
     hipEvent_t ev_sync = nullptr;                // orders the second stream after the first at the start of a batched commit
@@ -292,6 +296,9 @@ struct CommitKeep {
     std::vector<Tree> trees;
 };
 int32_t fri_commit_dev(sh_ctx* c, const fp* d_cw, size_t N, const sh_fri_params* prm, sh_transcript_cb cb, void* user,
-                       uint8_t* roots_out, uint64_t* last_out, size_t* last_len, CommitKeep* keep = nullptr);
+                       uint8_t* roots_out, uint64_t* last_out, size_t* last_len, CommitKeep* keep = nullptr, bool r0_leaves_hashed = false);
+// Host buffer -> device through the context's pinned staging ring: worker threads copy chunk i+1 into a pinned slot while the copy
+// engine moves chunk i; `after_chunk(first_elem, n_elems)` (may be empty) enqueues work on a chunk as soon as its copy is enqueued.
+int32_t upload_pipelined(sh_ctx* c, const uint64_t* host, size_t n_elems, fp* d_dst, const std::function<int32_t(size_t, size_t)>& after_chunk);
 struct PsCbState { sh_proofstream* ps; };
 int32_t ps_callback(void* user, uint32_t round, const uint8_t root[64], int32_t want_alpha, uint64_t alpha_out[2]);

@@ -250,7 +250,7 @@ int32_t sh_fri_prove(sh_ctx* c, const uint64_t* codeword, size_t N, const sh_fri
     if (!is_pow2(N) || ilog2(N) > SH_MAX_LOG_N) return sh_failf(SH_EINVAL, "sh_fri_prove: N must be a power of two <= 2^%d", SH_MAX_LOG_N);
     void* d;
     SHCHK(ensure_scratch(c, SCR_IO_C, N * 16, &d));
-    HIPCHK(hipMemcpyAsync(d, codeword, N * 16, hipMemcpyHostToDevice, c->stream));
+    SHCHK(upload_pipelined(c, codeword, N, (fp*)d, nullptr));
     return fri_prove_guarded(c, (const fp*)d, N, params, ps, top_level_indices, n_indices);
 }
 
