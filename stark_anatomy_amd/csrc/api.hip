@@ -80,20 +80,34 @@ int32_t get_pass_tables(sh_ctx* c, const NttPlan& plan, bool inverse, const fp* 
     return SH_OK;
 }
 
+// STARK_HIP_DEBUG_BT=1: SIGUSR1 makes the receiving thread print its native stack (tools/dump_threads.py sends it to every
+// thread of a stuck process and resolves the offsets) — the box has no debugger.
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+static void bt_handler(int) {
+    void* frames[48];
+    const int n = backtrace(frames, 48);
+    char head[64];
+    const int len = snprintf(head, sizeof head, "---- native stack of tid %ld\n", (long)syscall(SYS_gettid));
+    if (len > 0) (void)!write(2, head, (size_t)len);
+    backtrace_symbols_fd(frames, n, 2);
+}
+static void maybe_install_bt_handler() {
+    static std::once_flag once;
+    std::call_once(once, [] { if (getenv("STARK_HIP_DEBUG_BT")) { struct sigaction sa{}; sa.sa_handler = bt_handler; sa.sa_flags = SA_RESTART; sigaction(SIGUSR1, &sa, nullptr); } });
+}
+
 extern "C" {
 
 const char* sh_last_error(void) { return g_last_error.c_str(); }
 const char* sh_version(void) { return "stark_hip 0.1 (gfx950)"; }
 
-int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out) { return ctx_create_impl(device, hip_stream, false, out); }
-}  // extern "C"
-// high_priority: the context's own stream comes from the runtime's high-priority queue pool.  Streams share the few hardware
-// queues of the device (GPU_MAX_HW_QUEUES = 4) per priority level, and a kernel that waits for the host holds up whatever
-// another stream has put behind it in the same hardware queue: the second lock-step group of a batched commit asks for the
-// other pool so that its queue is never the one of the caller's (normal-priority) stream (api_fri.hip).
-int32_t ctx_create_impl(int32_t device, void* hip_stream, bool high_priority, sh_ctx** out) {
+int32_t sh_ctx_create(int32_t device, void* hip_stream, sh_ctx** out) {
     if (!out) return sh_fail(SH_EINVAL, "sh_ctx_create: null out");
     *out = nullptr;
+    maybe_install_bt_handler();
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -111,10 +125,7 @@ int32_t ctx_create_impl(int32_t device, void* hip_stream, bool high_priority, sh
     c->device = device;
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else {
-        int prio_least = 0, prio_greatest = 0;
-        if (high_priority && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_greatest != prio_least)
-            e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest);
-        else e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete c; return sh_failf(SH_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
@@ -128,14 +139,12 @@ int32_t ctx_create_impl(int32_t device, void* hip_stream, bool high_priority, sh
     *out = c;
     return SH_OK;
 }
-extern "C" {
 uint64_t sh_ctx_chain_retries(const sh_ctx* c) { return c ? c->chain_retries + (c->sub ? c->sub->chain_retries : 0) : 0; }
 int32_t sh_ctx_destroy(sh_ctx* c) {
     if (!c) return SH_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->sub) { (void)sh_ctx_destroy(c->sub); c->sub = nullptr; (void)hipSetDevice(c->device); }
-    if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
     delete c->pool;
     delete c->enqueuer;
     if (getenv("STARK_HIP_DEBUG")) fprintf(stderr, "[stark_hip] ctx %p: mailbox roots %u, fallbacks %llu\n", (void*)c, c->mail_seq, (unsigned long long)c->mail_fallbacks);
@@ -150,8 +159,7 @@ int32_t sh_ctx_destroy(sh_ctx* c) {
     if (c->h_chain) (void)hipHostFree(c->h_chain);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto& e : c->stage_ev) if (e) (void)hipEventDestroy(e);
-    for (auto& st : c->copy_stream) if (st) (void)hipStreamDestroy(st);
-    if (c->ev_upload0) (void)hipEventDestroy(c->ev_upload0);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->h_query) (void)hipHostFree(c->h_query);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

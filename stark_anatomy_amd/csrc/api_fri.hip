@@ -425,10 +425,17 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
 }
 
 // ------------------------------------------------------------------ host buffer -> device, pipelined
-// A pageable host buffer reaches the device through the runtime's own staging at ~29 GB/s (2^24 elements: 9.3 ms) and nothing
+// A pageable host buffer reaches the device through the runtime's own staging at ~20-29 GB/s (2^24 elements: 9-13 ms) and nothing
 // overlaps it; the caller's buffer cannot be pinned in place (hipHostRegister is refused for an ordinary user on the box).  So:
 // a ring of pinned slots per context; the context's worker threads copy chunk i+1 of the caller's buffer into a slot (memcpy
-// split over the threads) while the copy engine moves chunk i from its slot; `after_chunk` puts kernels behind a chunk's copy.
+// split over the threads) while the copy engine moves chunk i out of its slot on a stream of its own; `after_chunk` puts kernels
+// on the context's stream once a chunk has landed.
+// The two streams are ordered against each other by the HOST only (hipEventSynchronize on a chunk's copy before its kernels are
+// launched; the context's stream is drained before the first copy).  Stream-side waits (hipStreamWaitEvent in both directions) were
+// the first form, and hung: streams share the device's few hardware queues (GPU_MAX_HW_QUEUES = 4) once a process has more
+// streams than that, a barrier packet holds up everything behind it in its hardware queue whichever stream that belongs to, and a
+// barrier that waits for a copy queued behind it in the same hardware queue never ends (native stacks of the stuck process:
+// every thread inside a HIP wait; tools/run_with_dump.py).
 #define STAGE_SLOTS 4
 #define STAGE_SLOT_BYTES ((size_t)8 << 20)
 int32_t upload_pipelined(sh_ctx* c, const uint64_t* host, size_t n_elems, fp* d_dst, const std::function<int32_t(size_t, size_t)>& after_chunk) {
@@ -441,16 +448,7 @@ int32_t upload_pipelined(sh_ctx* c, const uint64_t* host, size_t n_elems, fp* d_
     if (!c->h_stage) {
         HIPCHK(hipHostMalloc((void**)&c->h_stage, STAGE_SLOTS * STAGE_SLOT_BYTES, hipHostMallocDefault));
         for (int i = 0; i < STAGE_SLOTS; ++i) HIPCHK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
-        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_upload0, hipEventDisableTiming));
-    }
-    // The copies run on a stream of their own; the context's stream waits for a chunk's event before the work on that chunk, so
-    // chunk i's kernels run beside chunk i+1's copy.  Measured at 2^24 / 2^20 (commit from pageable memory, ms): copies on the
-    // context's stream 10.2 / 1.26, one copy stream 8.2 / 1.20, two alternating 9.1 / 2.0 (STARK_HIP_UPLOAD_STREAMS=0|1|2).
-    static const unsigned n_copy_streams = [] { const char* e = getenv("STARK_HIP_UPLOAD_STREAMS"); const int v = e ? atoi(e) : 0; return (unsigned)(v >= 0 && v <= 2 && e ? v : 1); }();
-    if (n_copy_streams) {
-        HIPCHK(hipEventRecord(c->ev_upload0, c->stream));                   // the destination may still be read by work enqueued before
-        for (unsigned i = 0; i < n_copy_streams; ++i) HIPCHK(hipStreamWaitEvent(c->copy_stream[i], c->ev_upload0, 0));
+        HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     }
     if (!c->pool) {
         unsigned hw = std::thread::hardware_concurrency();
@@ -458,12 +456,20 @@ int32_t upload_pipelined(sh_ctx* c, const uint64_t* host, size_t n_elems, fp* d_
         try { c->pool = new SpinPool(hw > 1 ? hw - 1 : 0); } catch (const std::system_error&) { c->pool = new SpinPool(0); }
     }
     static const unsigned copy_threads = [] { const char* e = getenv("STARK_HIP_UPLOAD_THREADS"); const int v = e ? atoi(e) : 0; return (unsigned)(v >= 1 && v <= 8 ? v : 6); }();
+    HIPCHK(hipStreamSynchronize(c->stream));                              // the destination may still be read by work enqueued before
     c->pool->wake(copy_threads);
     struct Parker { SpinPool* p; ~Parker() { p->park(); } } parker{c->pool};
     const size_t chunk_bytes = bytes < 4 * STAGE_SLOT_BYTES ? ((bytes / 4 + 4095) & ~(size_t)4095) : STAGE_SLOT_BYTES;   // a short buffer still pipelines
     const size_t chunk_elems = chunk_bytes / sizeof(fp);
     const uint8_t* src = reinterpret_cast<const uint8_t*>(host);
-    size_t slot = 0, used = 0;
+    size_t slot = 0, used = 0, prev_e0 = 0, prev_ne = 0, prev_slot = 0;
+    bool have_prev = false;
+    auto land_prev = [&]() -> int32_t {                                   // the previous chunk's copy has finished: its kernels may go
+        if (!have_prev) return SH_OK;
+        HIPCHK(hipEventSynchronize(c->stage_ev[prev_slot]));
+        have_prev = false;
+        return after_chunk ? after_chunk(prev_e0, prev_ne) : SH_OK;
+    };
     for (size_t e0 = 0; e0 < n_elems; e0 += chunk_elems, slot = (slot + 1) % STAGE_SLOTS, ++used) {
         const size_t ne = n_elems - e0 < chunk_elems ? n_elems - e0 : chunk_elems, nb = ne * sizeof(fp);
         uint8_t* stage = c->h_stage + slot * STAGE_SLOT_BYTES;
@@ -473,13 +479,12 @@ int32_t upload_pipelined(sh_ctx* c, const uint64_t* host, size_t n_elems, fp* d_
             const size_t b0 = p0 << 12, b1 = (p1 << 12) < nb ? (p1 << 12) : nb;
             if (b0 < b1) memcpy(stage + b0, from + b0, b1 - b0);
         });
-        hipStream_t cs = n_copy_streams ? c->copy_stream[used % n_copy_streams] : c->stream;
-        HIPCHK(hipMemcpyAsync(d_dst + e0, stage, nb, hipMemcpyHostToDevice, cs));
-        HIPCHK(hipEventRecord(c->stage_ev[slot], cs));
-        if (n_copy_streams) HIPCHK(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
-        if (after_chunk) SHCHK(after_chunk(e0, ne));
+        HIPCHK(hipMemcpyAsync(d_dst + e0, stage, nb, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(hipEventRecord(c->stage_ev[slot], c->copy_stream));
+        SHCHK(land_prev());                                              // chunk i-1 was in flight while chunk i was staged
+        prev_e0 = e0; prev_ne = ne; prev_slot = slot; have_prev = true;
     }
-    return SH_OK;
+    return land_prev();                                                  // returns with every copy complete: nothing is left on the copy stream
 }
 // Upload of ONE codeword for a commit, with round 0's leaf hashing started on every chunk as it lands (the subtree digests of a
 // chunk are independent of the rest).  *hashed tells the driver that SCR_DIG_A already holds round 0's digests.
@@ -546,10 +551,7 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
         // the two groups stay in phase and the second thread only costs (1.25 -> 1.35 ms), so small batches keep one group.
         static const bool one_group = getenv("STARK_HIP_BATCH_ONE_GROUP") != nullptr;
         const size_t G = (!one_group && B >= 2 && R >= 2 && (B << log_N) >= ((size_t)1 << 23)) ? 2 : 1;   // a few large codewords too: 8 x 2^20, 2 x 2^24
-        if (G == 2 && (!c->sub || !c->ev_sync)) {                            // both or neither: a half-made pair would fail every later batch
-            if (!c->ev_sync) HIPCHK(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
-            if (!c->sub) SHCHK(ctx_create_impl(c->device, nullptr, true, &c->sub));      // its stream: the other priority pool, never the caller's hardware queue
-        }
+        if (G == 2 && !c->sub) SHCHK(sh_ctx_create(c->device, nullptr, &c->sub));
         unsigned T = std::thread::hardware_concurrency();
         if (T > 8) T = 8;
         if (T > B / 16) T = (unsigned)(B / 16);
@@ -593,11 +595,13 @@ static int32_t fri_commit_batch_dev(sh_ctx* c, const fp* d_cws, size_t B, size_t
         const auto t_core0 = std::chrono::steady_clock::now();
         SpinPool* pool0 = pool_of(c);
         park0.p = pool0;
+        if (getenv("STARK_HIP_DEBUG")) fprintf(stderr, "[stark_hip] batch: B=%zu N=2^%u, %zu group(s), %u transcript thread(s) per group\n", B, log_N, G, Tg);
         if (G == 1) SHCHK(commit_group(c, 0, B, pool0));
         else {
             const size_t B0 = B / 2, B1 = B - B0;
-            HIPCHK(hipEventRecord(c->ev_sync, c->stream));                  // the second stream starts after whatever produced the codewords
-            HIPCHK(hipStreamWaitEvent(c->sub->stream, c->ev_sync, 0));
+            // The second stream starts after whatever produced the codewords — ordered by the host, not by a stream-side wait on an
+            // event: streams share hardware queues, and a barrier packet of one stream in front of the other's packets can wait forever.
+            HIPCHK(hipStreamSynchronize(c->stream));
             SpinPool* pool1 = pool_of(c->sub);
             park1.p = pool1;
             int32_t rc1 = SH_OK;

@@ -203,11 +203,9 @@ struct sh_ctx {
     SpinPool* pool = nullptr;                    // transcript workers of batched commits (asleep between calls)
     uint8_t* h_stage = nullptr;                  // pinned staging ring of the host-buffer entry points (upload_pipelined, api_fri.hip)
     hipEvent_t stage_ev[8] = {};                 // slot i may be refilled once its last copy has left it
-    hipStream_t copy_stream[2] = {};             // the copies alternate between two streams of their own (two copy engines)
-    hipEvent_t ev_upload0 = nullptr;             // orders the copy streams after what the context's stream held before the upload
+    hipStream_t copy_stream = nullptr;           // the staged copies run on a stream of their own; only the HOST waits across the two streams
     ChainEnqueuer* enqueuer = nullptr;           // makes the HIP calls of a commit's rounds while the caller serves the chain
     sh_ctx* sub = nullptr;                       // second stream + buffers for the second lock-step group of a batched commit
-    hipEvent_t ev_sync = nullptr;                // orders the second stream after the first at the start of a batched commit
     uint8_t* h_query = nullptr;                  // pinned staging of the query phase (paths | values | indices | tree table)
     size_t h_query_bytes = 0;
     uint64_t chain_retries = 0;                  // rounds enqueued a second time because a wait kernel ran out of spin
@@ -231,7 +229,6 @@ static inline fp host_root_of_unity(uint32_t log_n) {
 #define QUAD_MAX_LOG_COUNT 17                  // from this many digests down a tree is reduced four-lanes-per-compression
 
 // api.hip
-int32_t ctx_create_impl(int32_t device, void* hip_stream, bool high_priority, sh_ctx** out);
 int32_t ensure_scratch(sh_ctx* c, int slot, size_t bytes, void** out);
 int32_t get_twiddles(sh_ctx* c, uint32_t log_n, bool inverse, const fp** out);
 int32_t get_pass_tables(sh_ctx* c, const NttPlan& plan, bool inverse, const fp* tw, NttPassTables* out);

@@ -47,15 +47,48 @@ FP_HD fp fp_from_u128(fp_u128 v) { return fp_from_u64x2((uint64_t)v, (uint64_t)(
 FP_HD fp_u128 fp_prime_u128() { return ((fp_u128)0xcb80000000000000ULL << 64) | 1u; }
 
 // (a + b) mod p for canonical a, b           [field.rs:57-68]
+// Device pass: 32-bit carry chains spelled out.  Through unsigned __int128 the compiler builds the comparisons from 64-bit compares
+// and selects every limb twice: 24 VALU instructions for an add and as many for a subtract; the chains below are 15 and 9 (the
+// subtract adds p back as "carry-in = borrow" on limb 0 and a masked top limb — p = 2^127·1.59… + 1 has only those two limbs).
+// A butterfly is one of each, so an NTT pass loses ~100 of its ~430 instructions per element.
 FP_HD fp fp_add(fp a, fp b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FP_ADDSUB_C)
+    uint32_t c, br, s0, s1, s2, s3, d0, d1, d2, d3;
+    s0 = __builtin_addc(a.w[0], b.w[0], 0u, &c);
+    s1 = __builtin_addc(a.w[1], b.w[1], c, &c);
+    s2 = __builtin_addc(a.w[2], b.w[2], c, &c);
+    s3 = __builtin_addc(a.w[3], b.w[3], c, &c);
+    d0 = __builtin_subc(s0, FP_P0, 0u, &br);
+    d1 = __builtin_subc(s1, 0u, br, &br);
+    d2 = __builtin_subc(s2, 0u, br, &br);
+    d3 = __builtin_subc(s3, FP_P3, br, &br);
+    const bool ge = c | !br;                     // the sum left 128 bits, or did not go below p
+    return fp_make(ge ? d0 : s0, ge ? d1 : s1, ge ? d2 : s2, ge ? d3 : s3);
+#else
     fp_u128 x = fp_to_u128(a), y = fp_to_u128(b), s = x + y, d = s - fp_prime_u128();
     bool ge = (s < x) | (s >= fp_prime_u128());
     return fp_from_u128(ge ? d : s);
+#endif
 }
 // (a - b) mod p for canonical a, b           [field.rs:70-82]
 FP_HD fp fp_sub(fp a, fp b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FP_ADDSUB_C)
+    uint32_t br, c, d0, d1, d2, d3;
+    d0 = __builtin_subc(a.w[0], b.w[0], 0u, &br);
+    d1 = __builtin_subc(a.w[1], b.w[1], br, &br);
+    d2 = __builtin_subc(a.w[2], b.w[2], br, &br);
+    d3 = __builtin_subc(a.w[3], b.w[3], br, &br);
+    const uint32_t m3 = br ? FP_P3 : 0u;         // + p when it went negative: limb 0 gets the borrow itself (p's limb 0 is 1)
+    fp r;
+    r.w[0] = __builtin_addc(d0, br, 0u, &c);
+    r.w[1] = __builtin_addc(d1, 0u, c, &c);
+    r.w[2] = __builtin_addc(d2, 0u, c, &c);
+    r.w[3] = d3 + m3 + c;
+    return r;
+#else
     fp_u128 x = fp_to_u128(a), y = fp_to_u128(b), d = x - y;
     return fp_from_u128(x < y ? d + fp_prime_u128() : d);
+#endif
 }
 FP_HD fp fp_neg(fp a) { return fp_is_zero(a) ? a : fp_from_u128(fp_prime_u128() - fp_to_u128(a)); }
 // a / 2 mod p

@@ -90,7 +90,10 @@ __device__ __forceinline__ void ntt_levels(fp* __restrict__ x, const fp* __restr
         for (int e = 0; e < (1 << S); ++e) x[(r0 + ((uint32_t)e << lo)) * rs + c] = v[e];
     }
 }
-__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams p) {
+#ifndef NTT_WAVES_PER_EU
+#define NTT_WAVES_PER_EU 8
+#endif
+__global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_EU) void k_ntt_pass(NttPassParams p) {      // 8 waves per SIMD = two workgroups per CU: at most 64 VGPRs
     extern __shared__ __align__(16) unsigned char lds_raw[];
     fp* x = reinterpret_cast<fp*>(lds_raw);
     const uint32_t R = 1u << p.log_r, C = 1u << p.log_c, T = R * C;
