@@ -5,10 +5,10 @@
    <prefix>_kernel_table_<workload>.md        SURVEY.md §8d: kernel, calls, avg us, algorithmic bytes, counter bytes
                                               (2·FETCH_SIZE + WRITE_SIZE, KiB -> bytes), GB/s, % of 8 TB/s, VALUBusy %, % of VALU peak
    <prefix>_timeline_<workload>.txt           kernel-by-kernel timeline of the workload
-usage: evidence_table.py [prefix=r02] [evidence dir]"""
+usage: evidence_table.py [prefix=r03] [evidence dir]"""
 import collections, csv, glob, os, shutil, sys
 
-prefix = sys.argv[1] if len(sys.argv) > 1 else "r02"
+prefix = sys.argv[1] if len(sys.argv) > 1 else "r03"
 EV = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/evidence"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
@@ -47,7 +47,8 @@ def commit_plan(log_N, B, alg):
             alg["k_round_wg"] += (32 * total if fold else 16 * total) + (16 * total if fold else 0) + (64 * (total >> 7) if lg > 7 else 64 * B)
         else:
             K = leaf_k(ilog2(total), lg)
-            name = ("k_fold_leaf_subtree" if fold else "k_leaf_subtree") + ("_staged" if K == 3 else "")
+            staged = K >= 1 and ((total >> K) & 255) == 0 and (not fold or lg >= 6 + K)      # hash_kernels.hip: launch_*_subtree
+            name = ("k_fold_leaf_subtree" if fold else "k_leaf_subtree") + ("_staged" if staged else "")
             alg[name] += (32 * total + 16 * total if fold else 16 * total) + 64 * (total >> K)
         rem = lg - K
         while rem > 0:
