@@ -97,7 +97,11 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_EU) void k_ntt_pass(NttP
     extern __shared__ __align__(16) unsigned char lds_raw[];
     fp* x = reinterpret_cast<fp*>(lds_raw);
     const uint32_t R = 1u << p.log_r, C = 1u << p.log_c, T = R * C;
+#ifdef NTT_PAD_ALL
+    const uint32_t rs = p.log_c ? C + 1 : C;
+#else
     const uint32_t rs = (p.is_final && p.log_c) ? C + 1 : C;      // padded row stride: transposed fill stays conflict-free
+#endif
     fp* twr = x + (size_t)R * rs;                                 // w_R^e, e < R/2 (Montgomery form)
     const uint32_t tid = threadIdx.x;
     const size_t tile = blockIdx.x & ((1u << p.log_tiles) - 1);
@@ -147,7 +151,11 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_EU) void k_ntt_pass(NttP
 
     // log2(R) decimation-in-frequency levels, NTT_RADIX_LOG at a time in registers: one LDS round trip and one
     // barrier per group of levels instead of per level.
+#ifdef NTT_SKIP_LEVELS
+    for (uint32_t hb = 0; hb > 0;) {            // timing experiment only: no butterflies (results are wrong)
+#else
     for (uint32_t hb = p.log_r; hb > 0;) {
+#endif
         const uint32_t S = hb < NTT_RADIX_LOG ? hb : NTT_RADIX_LOG, lo = hb - S;
         if (lo) ntt_levels<NTT_RADIX_LOG, false>(x, twr, rs, p.log_r, p.log_c, lo, T, tid, blockDim.x);      // lo > 0: a full group
         else switch (S) {
@@ -171,7 +179,11 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_EU) void k_ntt_pass(NttP
             const uint32_t k = __brev(r) >> (32 - p.log_r);
             fp v = x[r * rs + c];
             const size_t e = ((size_t)(colbase + c) * k) << tw_shift;
+#ifndef NTT_SKIP_TWIDDLE
             v = mont_mul(v, p.tw_pass ? p.tw_pass[(size_t)k * row_stride_in + colbase + c] : ntt_load_tw(p.tw, p.log_n, e));
+#else
+            (void)e;
+#endif
             out[base + (size_t)k * row_stride_in + c] = v;
         }
     } else {
@@ -200,6 +212,153 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_EU) void k_ntt_pass(NttP
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_ntt_pass_pipe — the same pass as a PERSISTENT workgroup with the next tile's loads in flight during this tile's levels.
+// Why: with the butterflies taken out, the three passes of a 2^24 transform still take 0.30 ms (the tile fills and drains: 5.4 TB/s),
+// with them 0.86 ms — the kernel above runs its memory phases and its arithmetic one after the other, and two workgroups per CU do
+// not interleave them well enough (profiles/r03_ntt_phase_experiment.txt).  Here a CU holds ONE workgroup of 1024 threads, which may
+// then use 128 VGPRs: 16 of them carry the thread's four elements of the NEXT tile, loaded right after the current tile has been
+// parked in LDS and consumed when the current tile has been stored.  The w_R table is built once per workgroup, not per tile.
+struct NttTileAddr {
+    size_t base, row_stride_in, xform_in, xform_out, chunk;
+    uint32_t colbase;
+};
+__device__ __forceinline__ NttTileAddr ntt_tile_addr(const NttPassParams& p, size_t t) {
+    NttTileAddr a;
+    const size_t tile = t & (((size_t)1 << p.log_tiles) - 1);
+    const size_t xform = (t >> p.log_tiles) << p.log_n;
+    a.xform_in = p.fuse_log_e ? xform >> p.fuse_log_e : xform;
+    a.xform_out = xform;
+    if (!p.is_final) {
+        const uint32_t log_mp = p.log_m - p.log_r;
+        const size_t chunks = (size_t)1 << (log_mp - p.log_c);
+        const size_t block = tile / chunks;
+        a.chunk = tile % chunks;
+        a.colbase = (uint32_t)(a.chunk << p.log_c);
+        a.base = (block << p.log_m) + a.colbase;
+        a.row_stride_in = (size_t)1 << log_mp;
+    } else {
+        const size_t chunks = (size_t)1 << (p.log_r0 - p.log_c);
+        const size_t mid = tile / chunks;
+        a.chunk = tile % chunks;
+        a.colbase = (uint32_t)(a.chunk << p.log_c);
+        a.base = mid << p.log_r;
+        a.row_stride_in = (size_t)1 << (p.log_n - p.log_r0);
+    }
+    return a;
+}
+#define NTT_PIPE_PER_THREAD ((1u << NTT_TILE_LOG) / NTT_THREADS)
+__global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass_pipe(NttPassParams p, uint32_t n_tiles) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    fp* x = reinterpret_cast<fp*>(lds_raw);
+    const uint32_t R = 1u << p.log_r, C = 1u << p.log_c, T = R * C;
+    const uint32_t rs = (p.is_final && p.log_c) ? C + 1 : C;
+    fp* twr = x + (size_t)R * rs;
+    fp* pc = twr + (R >> 1);                                      // fused LDE: offset^(colbase + c), c < C
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t e = tid; e < (R >> 1); e += blockDim.x) twr[e] = ntt_load_tw(p.tw, p.log_n, (size_t)e << (p.log_n - p.log_r));
+    const uint32_t r_n = p.fuse_log_e ? R >> p.fuse_log_e : R;   // fused LDE: rows below it hold coefficients, the rest is zero padding
+
+    // the thread's elements of tile tt -> registers (loads left in flight); T == NTT_THREADS · NTT_PIPE_PER_THREAD (launcher)
+    fp nxt0, nxt1, nxt2, nxt3;
+    static_assert(NTT_PIPE_PER_THREAD == 4, "four prefetch registers per thread");
+#define NTT_FETCH_ONE(dst, q)                                                                                   \
+    do {                                                                                                        \
+        const uint32_t idx_ = tid + (q) * NTT_THREADS;                                                          \
+        if (!p.is_final) {                                                                                      \
+            const uint32_t r_ = idx_ >> p.log_c, c_ = idx_ & (C - 1);                                           \
+            dst = r_ < r_n ? in_[fa.base + (size_t)r_ * fa.row_stride_in + c_] : fp_zero();                     \
+        } else {                                                                                                \
+            const uint32_t c_ = idx_ >> p.log_r, r_ = idx_ & (R - 1);                                           \
+            dst = in_[(size_t)(fa.colbase + c_) * fa.row_stride_in + fa.base + r_];                             \
+        }                                                                                                       \
+    } while (0)
+#define NTT_FETCH(tt)                                                                                           \
+    do {                                                                                                        \
+        const NttTileAddr fa = ntt_tile_addr(p, (tt));                                                          \
+        const fp* __restrict__ in_ = p.in + fa.xform_in;                                                        \
+        NTT_FETCH_ONE(nxt0, 0); NTT_FETCH_ONE(nxt1, 1); NTT_FETCH_ONE(nxt2, 2); NTT_FETCH_ONE(nxt3, 3);         \
+    } while (0)
+#define NTT_PARK_ONE(src, q)                                                                                    \
+    do {                                                                                                        \
+        const uint32_t idx_ = tid + (q) * NTT_THREADS;                                                          \
+        if (!p.is_final) {                                                                                      \
+            const uint32_t r_ = idx_ >> p.log_c, c_ = idx_ & (C - 1);                                           \
+            fp v_ = src;                                                                                        \
+            if (p.fuse_log_e && r_ < r_n) v_ = mont_mul(v_, mont_mul(p.pow_row[r_], pc[c_]));                   \
+            x[r_ * rs + c_] = v_;                                                                               \
+        } else {                                                                                                \
+            const uint32_t c_ = idx_ >> p.log_r, r_ = idx_ & (R - 1);                                           \
+            x[r_ * rs + c_] = src;                                                                              \
+        }                                                                                                       \
+    } while (0)
+    size_t t = blockIdx.x;
+    if (t < n_tiles) NTT_FETCH(t);
+    for (; t < n_tiles; t += gridDim.x) {
+        const NttTileAddr a = ntt_tile_addr(p, t);
+        fp* __restrict__ out = p.out + a.xform_out;
+        if (p.fuse_log_e) {
+            if (tid < C) pc[tid] = mont_mul(p.pow_chunk[a.chunk], p.pow_col[tid]);
+            __syncthreads();
+        }
+        // park the prefetched tile in LDS
+        NTT_PARK_ONE(nxt0, 0); NTT_PARK_ONE(nxt1, 1); NTT_PARK_ONE(nxt2, 2); NTT_PARK_ONE(nxt3, 3);
+        __syncthreads();
+        if (t + gridDim.x < n_tiles) NTT_FETCH(t + gridDim.x);   // in flight during the levels below
+
+        for (uint32_t hb = p.log_r; hb > 0;) {
+            const uint32_t S = hb < NTT_RADIX_LOG ? hb : NTT_RADIX_LOG, lo = hb - S;
+            if (lo) ntt_levels<NTT_RADIX_LOG, false>(x, twr, rs, p.log_r, p.log_c, lo, T, tid, blockDim.x);
+            else switch (S) {
+                case 1: ntt_levels<1, true>(x, twr, rs, p.log_r, p.log_c, 0, T, tid, blockDim.x); break;
+                case 2: ntt_levels<2, true>(x, twr, rs, p.log_r, p.log_c, 0, T, tid, blockDim.x); break;
+#if NTT_RADIX_LOG >= 3
+                case 3: ntt_levels<3, true>(x, twr, rs, p.log_r, p.log_c, 0, T, tid, blockDim.x); break;
+#endif
+            }
+            __syncthreads();
+            hb = lo;
+        }
+
+        if (!p.is_final) {
+            const uint32_t tw_shift = p.log_n - p.log_m;
+            for (uint32_t idx = tid; idx < T; idx += blockDim.x) {
+                const uint32_t r = idx >> p.log_c, c = idx & (C - 1);
+                const uint32_t k = __brev(r) >> (32 - p.log_r);
+                fp v = x[r * rs + c];
+                const size_t e = ((size_t)(a.colbase + c) * k) << tw_shift;
+                v = mont_mul(v, p.tw_pass ? p.tw_pass[(size_t)k * a.row_stride_in + a.colbase + c] : ntt_load_tw(p.tw, p.log_n, e));
+                out[a.base + (size_t)k * a.row_stride_in + c] = v;
+            }
+        } else {
+            const size_t tile = t & (((size_t)1 << p.log_tiles) - 1);
+            const size_t chunks = (size_t)1 << (p.log_r0 - p.log_c);
+            size_t mid = tile / chunks, midrev = 0;
+            uint32_t log_M = 0;
+            for (int q = (int)p.num_mid - 1; q >= 0; --q) { log_M += p.mid_bits[q]; }
+            {
+                uint32_t sh = 0;
+                size_t rem = mid;
+                for (int q = (int)p.num_mid - 1; q >= 0; --q) {
+                    const size_t dq = rem & (((size_t)1 << p.mid_bits[q]) - 1);
+                    rem >>= p.mid_bits[q];
+                    sh += p.mid_bits[q];
+                    midrev |= dq << (log_M - sh);
+                }
+            }
+            for (uint32_t idx = tid; idx < T; idx += blockDim.x) {
+                const uint32_t r = idx >> p.log_c, c = idx & (C - 1);
+                const uint32_t k = p.log_r ? (__brev(r) >> (32 - p.log_r)) : 0;
+                fp v = x[r * rs + c];
+                if (p.apply_scale) v = mont_mul(v, p.scale);
+                out[(size_t)(a.colbase + c) + ((((size_t)k << log_M) + midrev) << p.log_r0)] = v;
+            }
+        }
+        __syncthreads();                                         // the tile has left LDS: the next one may be parked
+    }
+}
+
 void ntt_make_plan(uint32_t log_n, NttPlan* plan) {
     plan->log_n = log_n;
     uint32_t P = log_n <= 8 ? 1 : (log_n + 7) / 8;
@@ -215,7 +374,11 @@ void ntt_make_plan(uint32_t log_n, NttPlan* plan) {
 
 static size_t pass_lds_bytes(uint32_t log_r, uint32_t log_c, bool is_final) {
     const size_t R = (size_t)1 << log_r, C = (size_t)1 << log_c;
+#ifdef NTT_PAD_ALL
+    const size_t rs = log_c ? C + 1 : C;
+#else
     const size_t rs = (is_final && log_c) ? C + 1 : C;
+#endif
     return (R * rs + (R >> 1) + 1 + C) * sizeof(fp);           // tile | w_R powers | C column powers of a fused LDE load
 }
 
@@ -271,6 +434,8 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
     if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
     const uint32_t P = plan.num_passes, log_n = plan.log_n;
@@ -308,6 +473,15 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         const size_t tiles = ((size_t)1 << p.log_tiles) * batch;
         if (tiles > 0x7fffffffu) return hipErrorInvalidValue;
         const size_t lds = pass_lds_bytes(p.log_r, p.log_c, is_final);
+        // Persistent, pipelined form for passes with enough full-size tiles to keep every CU's one workgroup busy for several tiles.
+        // Opt-in (STARK_HIP_NTT_PIPE=1): measured 0.862-0.872 ms against 0.822-0.827 ms for the plain form at 2^24 on one box —
+        // hiding the fills does not pay for halving the waves per SIMD (profiles/r03_ntt_phase_experiment.txt).
+        const char* pipe_env = getenv("STARK_HIP_NTT_PIPE");
+        const int pipe_mode = pipe_env ? atoi(pipe_env) : 0;
+        static const unsigned pipe_wgs = [] { const char* e = getenv("STARK_HIP_NTT_PIPE_WGS"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 256); }();
+        if (pipe_mode && (p.log_r + p.log_c) == NTT_TILE_LOG && tiles >= 4 * (size_t)pipe_wgs) {
+            hipLaunchKernelGGL(k_ntt_pass_pipe, dim3(pipe_wgs), dim3(NTT_THREADS), lds, s, p, (uint32_t)tiles);
+        } else
         hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS), lds, s, p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

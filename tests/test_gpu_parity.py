@@ -398,6 +398,19 @@ def test_fri_commit_2_24_properties(ctx):
     cur.free(); d.free()
 
 
+def test_ntt_pipelined_pass_matches(ctx, monkeypatch):
+    """STARK_HIP_NTT_PIPE=1 selects the persistent, prefetching form of the NTT pass (ntt_kernels.hip: k_ntt_pass_pipe; an opt-in that
+    measured slower, profiles/r03_ntt_phase_experiment.txt): same transform, same fused LDE, bit for bit."""
+    log_n = 22
+    x = co.splitmix_elems(222, 1 << log_n)
+    ref = sa.ntt(x, ctx=ctx)
+    ref_lde = sa.coset_lde(x[: 1 << 20], 2, G, ctx=ctx)
+    monkeypatch.setenv("STARK_HIP_NTT_PIPE", "1")
+    assert np.array_equal(sa.ntt(x, ctx=ctx), ref)
+    assert np.array_equal(sa.ntt(ref, inverse=True, ctx=ctx), x)
+    assert np.array_equal(sa.coset_lde(x[: 1 << 20], 2, G, ctx=ctx), ref_lde)
+
+
 # ------------------------------------------------------------------ batched commits (BASELINE config 4)
 @pytest.mark.parametrize("B,log_n", [(1, 10), (3, 7), (8, 14), (128, 14), (5, 1), (2, 18), (8, 19), (8, 20), (3, 22), (4, 22)])
 def test_fri_commit_batch_vs_oracle(ctx, B, log_n):
