@@ -222,7 +222,10 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
         *reinterpret_cast<volatile uint32_t*>(c->h_chain + lay.c0_seq(r)) = 0;
     }
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
-    HIPCHK(hipMemsetAsync(d_abort, 0, 4, c->stream));
+    // one memset: the workgroup counter of the counter-published launches (d_flag[16]; a commit that failed half way leaves it short of
+    // the host's running total) and the abort word (d_flag[32])
+    c->batch_done_total = 0;
+    HIPCHK(hipMemsetAsync(c->d_flag + 16, 0, 17 * 4, c->stream));
     const bool dbg = getenv("STARK_HIP_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     // debug runs pair the device's 100 MHz clock with the host's once per commit (a tiny kernel stamps pinned memory, the host
@@ -375,8 +378,7 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
             }
             for (int i = 0; i < 12; ++i) __atomic_store_n(h_abort + i, 0u, __ATOMIC_RELAXED);
             c->batch_done_total = 0;
-            HIPCHK(hipMemsetAsync(c->d_flag + 16, 0, 4, c->stream));
-            HIPCHK(hipMemsetAsync(d_abort, 0, 4, c->stream));
+            HIPCHK(hipMemsetAsync(c->d_flag + 16, 0, 17 * 4, c->stream));
             enq = r;
             if (helper) helper->post(enqueue_rest);
             else {
