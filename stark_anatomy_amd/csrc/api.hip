@@ -253,7 +253,7 @@ int32_t dev_ntt(sh_ctx* c, fp* d_data, uint32_t log_n, bool inverse, size_t batc
     void* scratch;
     SHCHK(ensure_scratch(c, SCR_WORK, n * sizeof(fp), &scratch));
     NttPlan plan;
-    ntt_make_plan(log_n, &plan);
+    ntt_make_plan(log_n, &plan, batch);
     fp scale = fp_mont_one();
     if (inverse) scale = fp_to_mont(fp_inv(fp_from_u64x2((uint64_t)1 << log_n, 0)));
     NttPassTables ptab;
@@ -357,7 +357,7 @@ int32_t sh_dev_coset_lde_batch(sh_ctx* c, const uint64_t* d_coeffs, size_t batch
         if (overlap && !(batch == 1 && ci == oi)) return sh_fail(SH_EINVAL, "sh_dev_coset_lde_batch: input and output overlap (in place is defined for batch == 1 with d_coeffs == d_out only)");
     }
     NttPlan plan;
-    ntt_make_plan(log_N, &plan);
+    ntt_make_plan(log_N, &plan, batch);
     NttLdeShape sh;
     static const bool no_fuse = getenv("STARK_NO_LDE_FUSE") != nullptr;
     if (no_fuse || d_coeffs == d_out || !ntt_lde_fusable(plan, log_expansion, &sh)) {

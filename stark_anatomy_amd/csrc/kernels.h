@@ -50,14 +50,18 @@ hipError_t launch_mul_periodic(const fp* in, const fp* factor, size_t mask, fp* 
 hipError_t launch_divmod_zerofier(const fp* f, size_t nf, size_t n, fp c_mont, fp* q, fp* r, hipStream_t s);
 
 // ---- ntt_kernels.hip ----
+#ifndef NTT_MAX_PASSES
 #define NTT_MAX_PASSES 4
+#endif
 #define NTT_TW_LO_BITS 12                    // lo table: w^i, i < 4096 ; hi table: w^(4096 i)
 struct NttPlan {
     uint32_t log_n;
     uint32_t num_passes;
     uint32_t bits[NTT_MAX_PASSES];           // radix bits per pass, sum == log_n; bits[0] is the most significant input digit
+    uint32_t tile_log;                       // elements per LDS tile (log2): 12, or 11 / 10 where 2^12 would leave most CUs without a tile
 };
-void ntt_make_plan(uint32_t log_n, NttPlan* plan);
+// batch: transforms per launch (the tile size is chosen for batch · 2^log_n elements)
+void ntt_make_plan(uint32_t log_n, NttPlan* plan, size_t batch = 1);
 // tw = [lo (min(n,4096)) | hi (max(n >> 12, 1))] Montgomery-form powers of the (inverse) n-th root.
 // scale_mont: Montgomery-form factor applied at the final store (R mod p == 1, or n^-1·R for the inverse).
 // `data` is transformed in place; `scratch` holds n elements.

@@ -52,6 +52,9 @@ __device__ __forceinline__ fp ntt_load_tw(const fp* __restrict__ tw, uint32_t lo
 #ifndef NTT_TILE_LOG
 #define NTT_TILE_LOG 12               // elements per tile (log2)
 #endif
+#ifndef NTT_MAX_PASS_BITS
+#define NTT_MAX_PASS_BITS 8           // radix bits per pass (rows of a tile = 2^bits)
+#endif
 #ifndef NTT_RADIX_LOG
 #define NTT_RADIX_LOG 2
 #endif
@@ -359,9 +362,9 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass_pipe(NttPassParams 
     }
 }
 
-void ntt_make_plan(uint32_t log_n, NttPlan* plan) {
+void ntt_make_plan(uint32_t log_n, NttPlan* plan, size_t batch) {
     plan->log_n = log_n;
-    uint32_t P = log_n <= 8 ? 1 : (log_n + 7) / 8;
+    uint32_t P = log_n <= NTT_MAX_PASS_BITS ? 1 : (log_n + NTT_MAX_PASS_BITS - 1) / NTT_MAX_PASS_BITS;
     plan->num_passes = P;
     for (uint32_t i = 0; i < NTT_MAX_PASSES; ++i) plan->bits[i] = 0;
     uint32_t rem = log_n;
@@ -370,6 +373,14 @@ void ntt_make_plan(uint32_t log_n, NttPlan* plan) {
         plan->bits[i] = b;
         rem -= b;
     }
+    // Tile size.  2^12 elements (64 KiB, 1024 threads, two per CU) is the best shape when every CU has tiles to spare; a 2^18
+    // transform has only 64 of them.  Halve the tile (and its workgroup) while fewer than 1024 tiles exist, as long as its rows
+    // stay >= 16 elements (256 bytes) long: 2^18 0.046 -> 0.030 ms (profiles/r03_ntt_phase_experiment.txt §6).
+    static const int forced = [] { const char* e = getenv("STARK_HIP_NTT_TILE_LOG"); return e ? atoi(e) : 0; }();
+    uint32_t tl = NTT_TILE_LOG;
+    while (tl > 10 && tl - 1 >= plan->bits[0] + 4 && (((batch ? batch : 1) << log_n) >> tl) < 1024) --tl;
+    if (forced >= 10 && forced <= NTT_TILE_LOG && (uint32_t)forced >= plan->bits[0] + 2) tl = (uint32_t)forced;
+    plan->tile_log = tl;
 }
 
 static size_t pass_lds_bytes(uint32_t log_r, uint32_t log_c, bool is_final) {
@@ -402,7 +413,7 @@ hipError_t launch_pow_table(fp* out, size_t count, fp base_mont, hipStream_t s) 
 bool ntt_lde_fusable(const NttPlan& plan, uint32_t log_expansion, NttLdeShape* shape) {
     if (plan.num_passes < 2 || log_expansion == 0 || log_expansion > plan.bits[0]) return false;
     const uint32_t log_r = plan.bits[0], log_mp = plan.log_n - log_r;
-    const uint32_t log_c = (NTT_TILE_LOG - log_r) < log_mp ? (NTT_TILE_LOG - log_r) : log_mp;
+    const uint32_t log_c = (plan.tile_log - log_r) < log_mp ? (plan.tile_log - log_r) : log_mp;
     shape->rows = (size_t)1 << (log_r - log_expansion);
     shape->chunks = (size_t)1 << (log_mp - log_c);
     shape->cols = (size_t)1 << log_c;
@@ -452,7 +463,7 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         if (!is_final) {
             p.log_m = log_n - consumed;
             const uint32_t log_mp = p.log_m - p.log_r;
-            p.log_c = (NTT_TILE_LOG - p.log_r) < log_mp ? (NTT_TILE_LOG - p.log_r) : log_mp;
+            p.log_c = (plan.tile_log - p.log_r) < log_mp ? (plan.tile_log - p.log_r) : log_mp;
             p.tw_pass = ptab ? ptab->t[pi] : nullptr;
             p.in = data;                                               // non-final passes work in place on `data` ...
             p.out = (pi + 2 == P) ? scratch : data;                    // ... except the last one, which lands in scratch
@@ -462,7 +473,7 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
             }
         } else {
             p.log_r0 = (P >= 2) ? plan.bits[0] : 0;
-            p.log_c = (NTT_TILE_LOG - p.log_r) < p.log_r0 ? (NTT_TILE_LOG - p.log_r) : p.log_r0;
+            p.log_c = (plan.tile_log - p.log_r) < p.log_r0 ? (plan.tile_log - p.log_r) : p.log_r0;
             p.num_mid = (P >= 2) ? P - 2 : 0;
             for (uint32_t q = 0; q < p.num_mid; ++q) p.mid_bits[q] = plan.bits[1 + q];
             p.apply_scale = apply_scale ? 1 : 0;
@@ -482,7 +493,7 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         if (pipe_mode && (p.log_r + p.log_c) == NTT_TILE_LOG && tiles >= 4 * (size_t)pipe_wgs) {
             hipLaunchKernelGGL(k_ntt_pass_pipe, dim3(pipe_wgs), dim3(NTT_THREADS), lds, s, p, (uint32_t)tiles);
         } else
-        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS), lds, s, p);
+        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS >> (NTT_TILE_LOG - plan.tile_log)), lds, s, p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         consumed += p.log_r;
