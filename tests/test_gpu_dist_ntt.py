@@ -247,13 +247,14 @@ if g == 0:
 '''
 
 
-@pytest.mark.parametrize("log_n,mode", [(14, "native"), (14, "python"), (22, "native")])
-def test_two_ranks_one_gpu_gloo(tmp_path, log_n, mode):
+@pytest.mark.parametrize("log_n,mode,ranks", [(14, "native", 2), (14, "python", 2), (22, "native", 2), (18, "native", 4), (20, "native", 8)])
+def test_ranks_on_one_gpu_gloo(tmp_path, log_n, mode, ranks):
     """14: against the oracle.  22 (config 5's shape at a size two ranks on one card finish in seconds): against the
     single-GPU NTT / LDE / commit of the product, which are themselves oracle-checked at that size.
     native: the C++ orchestration (sh_dist_*) with its transport operations served by gloo-backed callbacks that stage through
     host memory — every exchange, regroup and sub-root gather of the product code with two real ranks; python: dist_ntt.py's
-    own orchestration over the same kernels."""
+    own orchestration over the same kernels.  4 and 8 ranks: the rank counts of the scaling runs, which no RCCL run on a one-GPU
+    box can rehearse — slice sizes, sharded round counts and the regroup pattern differ with P."""
     n = 1 << log_n
     x = co.splitmix_elems(99, n)
     np.save(tmp_path / "in.npy", x)
@@ -264,8 +265,8 @@ def test_two_ranks_one_gpu_gloo(tmp_path, log_n, mode):
                PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
     if mode == "python":
         env["STARK_DIST_PYTHON"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", str(script)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29731 + ranks), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     parts = pickle.load(open(out, "rb"))
