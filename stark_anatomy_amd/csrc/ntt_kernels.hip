@@ -20,6 +20,10 @@
 // Since the last level group is a specialisation of its own (ntt_levels<S, true>) the kernel needs 60, and the asm form
 // wins: 0.95 -> 0.90 ms (-DFP_MONT_MUL_C brings the C form back).
 #include "kernels.h"
+#ifdef NTT_TRACE
+#include <vector>
+#include <cstdio>
+#endif
 
 struct NttPassParams {
     const fp* in;
@@ -37,6 +41,9 @@ struct NttPassParams {
     uint32_t fuse_log_e;
     const fp *pow_row, *pow_chunk, *pow_col;
     const fp* tw_pass;            // non-final pass: direct table of its inter-pass twiddles, [k][col] (NttPassTables), or null
+#ifdef NTT_TRACE
+    unsigned long long* trace;    // experiment build: per workgroup 8 stamps of the 100 MHz clock (start, filled, 4 level groups, drained) + XCC/CU id
+#endif
 };
 
 __device__ __forceinline__ fp ntt_load_tw(const fp* __restrict__ tw, uint32_t log_n, size_t e) {
@@ -107,6 +114,14 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_EU) void k_ntt_pass(NttP
 #endif
     fp* twr = x + (size_t)R * rs;                                 // w_R^e, e < R/2 (Montgomery form)
     const uint32_t tid = threadIdx.x;
+#ifdef NTT_TRACE
+#define NTT_STAMP(i) do { if (p.trace && tid == 0) p.trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    uint32_t stamp_i = 2;
+    NTT_STAMP(0);
+    if (p.trace && tid == 0) p.trace[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
+#else
+#define NTT_STAMP(i) do { } while (0)
+#endif
     const size_t tile = blockIdx.x & ((1u << p.log_tiles) - 1);
     const size_t xform = (size_t)(blockIdx.x >> p.log_tiles) << p.log_n;   // batched: transforms are contiguous
     const fp* __restrict__ in = p.in + (p.fuse_log_e ? xform >> p.fuse_log_e : xform);   // fused LDE: the inputs are the short coefficient vectors
@@ -151,6 +166,7 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_EU) void k_ntt_pass(NttP
         }
     }
     __syncthreads();
+    NTT_STAMP(1);
 
     // log2(R) decimation-in-frequency levels, NTT_RADIX_LOG at a time in registers: one LDS round trip and one
     // barrier per group of levels instead of per level.
@@ -172,6 +188,9 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_EU) void k_ntt_pass(NttP
 #endif
         }
         __syncthreads();
+#ifdef NTT_TRACE
+        if (stamp_i < 6) { NTT_STAMP(stamp_i); ++stamp_i; }
+#endif
         hb = lo;
     }
 
@@ -213,6 +232,10 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_EU) void k_ntt_pass(NttP
             out[(size_t)(colbase + c) + ((((size_t)k << log_M) + midrev) << p.log_r0)] = v;
         }
     }
+#ifdef NTT_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NTT_STAMP(6);
+#endif
 }
 
 
@@ -492,8 +515,42 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         static const unsigned pipe_wgs = [] { const char* e = getenv("STARK_HIP_NTT_PIPE_WGS"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 256); }();
         if (pipe_mode && (p.log_r + p.log_c) == NTT_TILE_LOG && tiles >= 4 * (size_t)pipe_wgs) {
             hipLaunchKernelGGL(k_ntt_pass_pipe, dim3(pipe_wgs), dim3(NTT_THREADS), lds, s, p, (uint32_t)tiles);
-        } else
+        } else {
+#ifdef NTT_TRACE
+        static unsigned long long* d_trace = nullptr;
+        static int trace_left = getenv("STARK_HIP_NTT_TRACE") ? atoi(getenv("STARK_HIP_NTT_TRACE")) : 0;
+        const bool tracing = trace_left > 0 && tiles >= 1024 && tiles <= 8192;
+        if (tracing && !d_trace && hipMalloc(&d_trace, 8192 * 64) != hipSuccess) return hipErrorOutOfMemory;
+        p.trace = tracing ? d_trace : nullptr;
+        static const size_t lds_extra = getenv("STARK_HIP_NTT_LDS_EXTRA") ? (size_t)atoi(getenv("STARK_HIP_NTT_LDS_EXTRA")) : 0;    // e.g. 24576: one workgroup per CU
+        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS >> (NTT_TILE_LOG - plan.tile_log)), lds + lds_extra, s, p);
+#else
         hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS >> (NTT_TILE_LOG - plan.tile_log)), lds, s, p);
+#endif
+#ifdef NTT_TRACE
+        if (tracing) {
+            --trace_left;
+            std::vector<unsigned long long> h(tiles * 8);
+            if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(h.data(), d_trace, tiles * 64, hipMemcpyDeviceToHost) != hipSuccess) return hipErrorUnknown;
+            unsigned long long t_min = ~0ull, t_max = 0;
+            for (size_t w = 0; w < tiles; ++w) { if (h[w * 8] < t_min) t_min = h[w * 8]; if (h[w * 8 + 6] > t_max) t_max = h[w * 8 + 6]; }
+            double sum[7] = {0};
+            for (size_t w = 0; w < tiles; ++w) for (int i = 1; i < 7; ++i) sum[i] += (double)(h[w * 8 + i] - h[w * 8 + i - 1]) / 100.0;
+            fprintf(stderr, "[ntt trace] pass %u (%s, R=2^%u C=2^%u, %zu tiles): kernel %.1f us; per workgroup (us, mean): fill %.2f | groups %.2f %.2f %.2f %.2f | twiddle+drain %.2f | total %.2f\n", pi,
+                    is_final ? "final" : "non-final", p.log_r, p.log_c, tiles, (double)(t_max - t_min) / 100.0, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[5] / tiles,
+                    sum[6] / tiles, (sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6]) / tiles);
+            // the first 6 workgroups that ran on the CU of workgroup 0: start / end offsets
+            const unsigned long long cu0 = h[7];
+            int shown = 0;
+            for (size_t w = 0; w < tiles && shown < 10; ++w) if (h[w * 8 + 7] == cu0) {
+                fprintf(stderr, "[ntt trace]   wg %5zu on that CU: start %7.2f filled %7.2f g %7.2f %7.2f %7.2f %7.2f end %7.2f\n", w, (double)(h[w * 8] - t_min) / 100.0, (double)(h[w * 8 + 1] - t_min) / 100.0,
+                        (double)(h[w * 8 + 2] - t_min) / 100.0, (double)(h[w * 8 + 3] - t_min) / 100.0, (double)(h[w * 8 + 4] - t_min) / 100.0, (double)(h[w * 8 + 5] - t_min) / 100.0,
+                        (double)(h[w * 8 + 6] - t_min) / 100.0);
+                ++shown;
+            }
+        }
+#endif
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         consumed += p.log_r;
