@@ -157,6 +157,7 @@ int32_t sh_ctx_destroy(sh_ctx* c) {
     if (c->h_mail) (void)hipHostFree(c->h_mail);
     if (c->h_batch) (void)hipHostFree(c->h_batch);
     if (c->h_chain) (void)hipHostFree(c->h_chain);
+    if (c->c0_buf) (void)hipFree(c->c0_buf);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto& e : c->stage_ev) if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);

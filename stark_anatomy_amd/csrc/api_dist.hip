@@ -393,7 +393,7 @@ static int32_t dist_fri_commit_impl(sh_dist* d, const fp* d_local, size_t N, con
     int32_t rc_tail = SH_OK;
     if (S) {
         const ChainLayout lay(1, S, 0);
-        SHCHK(ensure_chain(c, lay.total));
+        SHCHK(ensure_chain(c, lay.total, lay.off_last));
         uint32_t gen = (c->chain_gen + 1) & 0x7fffffffu;
         if (gen == 0) gen = 1;
         c->chain_gen = gen;
@@ -407,13 +407,13 @@ static int32_t dist_fri_commit_impl(sh_dist* d, const fp* d_local, size_t N, con
         for (int i = 0; i < 16; ++i) h_abort[i] = 0;
         for (uint32_t r = 0; r < S; ++r) {
             *reinterpret_cast<volatile uint32_t*>(c->h_chain + lay.root_seq(r)) = 0;
-            *reinterpret_cast<volatile uint32_t*>(c->h_chain + lay.c0_seq(r)) = 0;
+            *reinterpret_cast<volatile uint32_t*>(c->c0_host + lay.c0_seq(r)) = 0;
         }
         __atomic_thread_fence(__ATOMIC_SEQ_CST);
         HIPCHK(hipMemsetAsync(d_abort, 0, 4, c->stream));
 
         auto wait_c0 = [&](uint32_t r) -> int32_t {              // the kernels behind it read c0(r) from d_c0
-            HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r)), gen, reinterpret_cast<const fp*>(c->d_chain + lay.c0(r)), (fp*)d_c0, 1,
+            HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->c0_dev + lay.c0_seq(r)), gen, reinterpret_cast<const fp*>(c->c0_dev + lay.c0(r)), (fp*)d_c0, 1,
                                   d_abort, hd_abort, timeout_ticks, c->stream));
             return SH_OK;
         };
@@ -489,9 +489,11 @@ static int32_t dist_fri_commit_impl(sh_dist* d, const fp* d_local, size_t N, con
             uint64_t aw[2];
             if (ps_callback(&st, r, roots_out + 64 * (size_t)r, 1, aw) != 0) return sh_failf(SH_ECALLBACK, "sh_dist_fri_commit: transcript update failed in round %u", r);
             const fp alpha = fp_load_host(aw);
-            fp* h_c0 = reinterpret_cast<fp*>(c->h_chain + lay.c0(r));
+            fp* h_c0 = reinterpret_cast<fp*>(c->c0_host + lay.c0(r));
             h_c0[0] = mont_mul(alpha, fp_to_mont(fp_to_mont(fp_mul(inv2, off_inv))));     // c0 = alpha · 2^-1 · offset_r^-1, Montgomery form
-            __atomic_store_n(reinterpret_cast<uint32_t*>(c->h_chain + lay.c0_seq(r)), gen, __ATOMIC_RELEASE);
+            c0_flush();
+            __atomic_store_n(reinterpret_cast<uint32_t*>(c->c0_host + lay.c0_seq(r)), gen, __ATOMIC_RELEASE);
+            c0_flush();
             guard.next_c0 = r + 1;
             off_inv = fp_mul(off_inv, off_inv);
         }

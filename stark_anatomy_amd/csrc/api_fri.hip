@@ -11,14 +11,33 @@ int32_t check_params(const sh_fri_params* p, fp* offset) {
     return SH_OK;
 }
 // ------------------------------------------------------------------ the commit chain (ChainLayout, ChainGuard: api_internal.h)
-int32_t ensure_chain(sh_ctx* c, size_t bytes) {
-    if (c->chain_bytes >= bytes) return SH_OK;
-    if (c->h_chain) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->h_chain)); c->h_chain = nullptr; c->d_chain = nullptr; c->chain_bytes = 0; }
-    const size_t want = (bytes + 4095) & ~(size_t)4095;
-    HIPCHK(hipHostMalloc((void**)&c->h_chain, want, hipHostMallocMapped | hipHostMallocCoherent));
-    memset(c->h_chain, 0, want);
-    HIPCHK(hipHostGetDevicePointer((void**)&c->d_chain, c->h_chain, 0));
-    c->chain_bytes = want;
+int32_t ensure_chain(sh_ctx* c, size_t bytes, size_t c0_end) {
+    if (c->chain_bytes < bytes) {
+        if (c->h_chain) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->h_chain)); c->h_chain = nullptr; c->d_chain = nullptr; c->chain_bytes = 0; }
+        const size_t want = (bytes + 4095) & ~(size_t)4095;
+        HIPCHK(hipHostMalloc((void**)&c->h_chain, want, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(c->h_chain, 0, want);
+        HIPCHK(hipHostGetDevicePointer((void**)&c->d_chain, c->h_chain, 0));
+        c->chain_bytes = want;
+    }
+    // The c0 records: on the card when the host can store into device memory (large BAR).  The GPU then polls its own memory instead
+    // of reading host memory over PCIe for every poll, and reads the constants locally once they are there: ~1.5 us less per
+    // hand-off (tools/bar_probe.hip: host store -> GPU sees it -> GPU store -> host sees it, 2.43 us with a pinned host word, 1.91 us
+    // with an uncached device word; the constants' own PCIe read on top in the pinned form).
+    static const bool pinned_c0 = getenv("STARK_HIP_C0_PINNED") != nullptr;
+    int large_bar = 0;
+    if (!pinned_c0) (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device);
+    if (large_bar && c->c0_bytes < c0_end) {
+        if (c->c0_buf) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->c0_buf)); c->c0_buf = nullptr; c->c0_bytes = 0; }
+        const size_t want = (c0_end + 65535) & ~(size_t)65535;
+        if (hipExtMallocWithFlags((void**)&c->c0_buf, want, hipDeviceMallocUncached) == hipSuccess) {
+            HIPCHK(hipMemsetAsync(c->c0_buf, 0, want, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->c0_bytes = want;
+        } else { (void)hipGetLastError(); c->c0_buf = nullptr; }
+    }
+    if (large_bar && c->c0_buf) c->c0_host = c->c0_dev = c->c0_buf;
+    else { c->c0_host = c->h_chain; c->c0_dev = c->d_chain; }
     return SH_OK;
 }
 // Wait for a root record.  NO HIP call on this path: while the host sits here the next round's kernel may already be spinning
@@ -45,12 +64,18 @@ int32_t wait_seq(sh_ctx* c, const uint32_t* flag, uint32_t gen, uint32_t round, 
         __builtin_ia32_pause();
     }
 }
+// header word 3 of a give-up = (address of the sequence word - address of the header) mod 2^31: back to the word's layout offset,
+// whichever buffer the c0 records are in
+static uint32_t c0_offset_of(const sh_ctx* c, uint32_t word3) {
+    const uint32_t delta = (uint32_t)((uintptr_t)c->c0_dev - (uintptr_t)c->d_chain);
+    return ((word3 & 0x7fffffffu) - delta) & 0x7fffffffu;
+}
 // what the wait kernel that gave up last left in the chain header (round_kernels.hip)
 static int32_t fail_gave_up(sh_ctx* c, uint32_t round, uint32_t gen, uint32_t retries) {
     const volatile uint32_t* hd = reinterpret_cast<volatile uint32_t*>(c->h_chain);
     return sh_failf(SH_EHIP, "fri_commit: round %u: the GPU still does not see its challenge after %u re-launches (gen %u; kernel waited for gen %u, record held %u, chain offset 0x%x%s, "
-                    "block %u of %u, %u polls, xcc %u; the host sees %u there now)", round, retries, gen, hd[1], hd[2], hd[3] & 0x7fffffffu, (hd[3] >> 31) ? " [k_round_wg]" : " [k_wait_c0]",
-                    hd[4] & 0xffff, hd[4] >> 16, hd[5], hd[6], *reinterpret_cast<volatile uint32_t*>(c->h_chain + (hd[3] & 0x7fffffffu)));
+                    "block %u of %u, %u polls, xcc %u; the host sees %u there now)", round, retries, gen, hd[1], hd[2], c0_offset_of(c, hd[3]), (hd[3] >> 31) ? " [k_round_wg]" : " [k_wait_c0]",
+                    hd[4] & 0xffff, hd[4] >> 16, hd[5], hd[6], *reinterpret_cast<volatile uint32_t*>(c->c0_host + c0_offset_of(c, hd[3])));
 }
 
 // How many levels the next launch of a forest reduction takes off B trees of 2^lg digests each, and with which kernel.
@@ -154,7 +179,7 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
     const size_t last_bytes = B * L_last * sizeof(fp);
     const bool stage_last = last_bytes <= ((size_t)64 << 20);
     const ChainLayout lay(B, R, stage_last ? last_bytes : 0);
-    SHCHK(ensure_chain(c, lay.total));
+    SHCHK(ensure_chain(c, lay.total, lay.off_last));
     const fp* tw_inv;
     SHCHK(get_twiddles(c, log_N, true, &tw_inv));
     void *bufX = nullptr, *bufY = nullptr, *arena = nullptr, *digA, *digB, *d_c0;
@@ -219,9 +244,10 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
     // ends with a synchronise), so nothing reads these words now: lower them all.
     for (uint32_t r = 0; r < R; ++r) {
         *reinterpret_cast<volatile uint32_t*>(c->h_chain + lay.root_seq(r)) = 0;
-        *reinterpret_cast<volatile uint32_t*>(c->h_chain + lay.c0_seq(r)) = 0;
+        *reinterpret_cast<volatile uint32_t*>(c->c0_host + lay.c0_seq(r)) = 0;
     }
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    c0_flush();
     // one memset: the workgroup counter of the counter-published launches (d_flag[16]; a commit that failed half way leaves it short of
     // the host's running total) and the abort word (d_flag[32])
     c->batch_done_total = 0;
@@ -265,10 +291,10 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
             if (lg_tree <= 7 && blocks > 1 && !roots_via_kernel) { c->batch_done_total += (uint32_t)blocks; target = c->batch_done_total; }
             const bool poll_inside = fold && B == 1 && blocks == 1;        // else a wait kernel first: exactly one workgroup ever polls host memory (round_kernels.hip)
             if (fold && !poll_inside)
-                HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)),
+                HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->c0_dev + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->c0_dev + lay.c0(r - 1)),
                                       (fp*)d_c0, B, d_abort, hd_abort, timeout_ticks, c->stream));
-            HIPCHK(launch_round_wg(fold, in, out, lg_tree, B, poll_inside ? reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)) : nullptr, gen,
-                                   poll_inside ? reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)) : nullptr, (const fp*)d_c0, d_abort, hd_abort, timeout_ticks, tw_inv, log_N,
+            HIPCHK(launch_round_wg(fold, in, out, lg_tree, B, poll_inside ? reinterpret_cast<const uint32_t*>(c->c0_dev + lay.c0_seq(r - 1)) : nullptr, gen,
+                                   poll_inside ? reinterpret_cast<const fp*>(c->c0_dev + lay.c0(r - 1)) : nullptr, (const fp*)d_c0, d_abort, hd_abort, timeout_ticks, tw_inv, log_N,
                                    fold ? r - 1 : 0, roots_via_kernel ? d_roots : first, reinterpret_cast<uint64_t*>(rec), reinterpret_cast<uint32_t*>(rec + B * 64),
                                    roots_via_kernel ? nullptr : c->d_flag + 16, target, c->stream));
             if (roots_via_kernel) HIPCHK(launch_publish_digests(d_roots, B, reinterpret_cast<uint64_t*>(rec), reinterpret_cast<uint32_t*>(rec + B * 64), gen, c->stream, d_abort));
@@ -290,7 +316,7 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
             fp* next = cw_of(r);
             if (sh.small) SHCHK(small_round(true, in, next, ilog2(half)));
             else {
-                HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->d_chain + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->d_chain + lay.c0(r - 1)),
+                HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->c0_dev + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->c0_dev + lay.c0(r - 1)),
                                       (fp*)d_c0, B, d_abort, hd_abort, timeout_ticks, c->stream));
                 const uint32_t K = sh.K;
                 digest64* dst = first ? first : c->d_root;
@@ -360,7 +386,7 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
                 const volatile uint32_t* hd = h_abort;
                 const uint64_t tk1 = *reinterpret_cast<const volatile uint64_t*>(h_abort + 8), tk0 = *reinterpret_cast<const volatile uint64_t*>(h_abort + 10);
                 const double g1 = cal_host_us + ((double)(int64_t)(tk1 - cal_ticks)) / 100.0 - t_start, g0 = cal_host_us + ((double)(int64_t)(tk0 - cal_ticks)) / 100.0 - t_start;
-                const uint32_t off = hd[3] & 0x7fffffffu;
+                const uint32_t off = c0_offset_of(c, hd[3]);
                 const uint32_t k = (uint32_t)((off - lay.off_c0) / lay.rec_c0);
                 fprintf(stderr, "[stark_hip] GAVE UP: %s waited for c0(%u) (gen %u) from t=%.1f to t=%.1f us (%u polls, xcc %u); it read %u (polling load), %u (non-temporal load), neighbour word %u.\n"
                                 "[stark_hip]   host: c0(%u) %s; now t=%.1f, serving round %u; this thread's last enqueue: round-%u slot, t=%.1f .. %.1f us%s\n",
@@ -391,13 +417,15 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
         const bool want = r + 1 < R;
         SHCHK(fn(r, c->h_chain + lay.roots(r), want, alpha.data()));
         if (want) {
-            fp* h_c0 = reinterpret_cast<fp*>(c->h_chain + lay.c0(r));
+            fp* h_c0 = reinterpret_cast<fp*>(c->c0_host + lay.c0(r));
             const fp k_rr = fp_to_mont(fp_to_mont(fp_mul(inv2, off_inv)));            // 2^-1 · offset_r^-1 · R^2: one multiply per codeword below
             for (size_t b = 0; b < B; ++b) {
                 if (!fp_is_canonical(alpha[b])) return sh_fail(SH_EINVAL, "fri_commit: callback returned a non-canonical alpha");
                 h_c0[b] = mont_mul(alpha[b], k_rr);                                   // c0 = alpha · 2^-1 · offset_r^-1, in Montgomery form
             }
-            __atomic_store_n(reinterpret_cast<uint32_t*>(c->h_chain + lay.c0_seq(r)), gen, __ATOMIC_RELEASE);
+            c0_flush();                                                               // the constants before the sequence word, also through a write-combining BAR mapping
+            __atomic_store_n(reinterpret_cast<uint32_t*>(c->c0_host + lay.c0_seq(r)), gen, __ATOMIC_RELEASE);
+            c0_flush();
             if (dbg) t_pub[r] = now();
             guard.next_c0 = r + 1;
             off_inv = fp_mul(off_inv, off_inv);

@@ -200,6 +200,12 @@ struct sh_ctx {
     uint8_t* h_chain = nullptr;                  // pinned, device-mapped: root / fold-constant records of a commit's rounds (api_fri.hip)
     uint8_t* d_chain = nullptr;                  // device view of h_chain
     size_t chain_bytes = 0;
+    // Where the fold-constant (c0) records live, at the chain layout's offsets: in device memory that the host writes through the
+    // PCIe BAR (c0_buf: uncached allocation; the GPU's polls and its read of the constants stay on the card), or — no large BAR, or
+    // STARK_HIP_C0_PINNED=1 — in the pinned chain buffer itself (c0_host == h_chain, c0_dev == d_chain).
+    uint8_t* c0_buf = nullptr;
+    size_t c0_bytes = 0;
+    uint8_t *c0_host = nullptr, *c0_dev = nullptr;
     SpinPool* pool = nullptr;                    // transcript workers of batched commits (asleep between calls)
     uint8_t* h_stage = nullptr;                  // pinned staging ring of the host-buffer entry points (upload_pipelined, api_fri.hip)
     hipEvent_t stage_ev[8] = {};                 // slot i may be refilled once its last copy has left it
@@ -266,18 +272,22 @@ struct ChainLayout {
 };
 // Releases the GPU on every exit path once kernels that wait for the host are in flight: publishes "abort" in every c0
 // record not yet published and drains the stream.
+// Stores into the c0 records may go through a write-combining mapping of the BAR: push them out, in order, now.
+static inline void c0_flush() { __builtin_ia32_sfence(); }
 struct ChainGuard {
     sh_ctx* c; const ChainLayout* lay; uint32_t gen; size_t next_c0 = 0, waits = 0; bool armed = false;   // waits: c0 records 0..waits-1 may have a kernel waiting
     ChainEnqueuer* helper = nullptr;               // a posted job refers to the caller's frame: it must have returned before the frame goes
     ~ChainGuard() {
         if (!armed) return;
         for (size_t r = next_c0; r < waits; ++r)
-            __atomic_store_n(reinterpret_cast<uint32_t*>(c->h_chain + lay->c0_seq(r)), gen | 0x80000000u, __ATOMIC_RELEASE);
+            __atomic_store_n(reinterpret_cast<uint32_t*>(c->c0_host + lay->c0_seq(r)), gen | 0x80000000u, __ATOMIC_RELEASE);
+        c0_flush();
         if (helper) (void)helper->wait(nullptr);
         (void)hipStreamSynchronize(c->stream);
     }
 };
-int32_t ensure_chain(sh_ctx* c, size_t bytes);
+// bytes: the whole layout (pinned buffer); c0_end: the layout's offset behind the last c0 record (what a device-side copy must hold)
+int32_t ensure_chain(sh_ctx* c, size_t bytes, size_t c0_end);
 // Wait for a sequence word of the chain to carry `gen` without any HIP call: SH_OK, WAIT_RETRY (a wait kernel gave up), WAIT_ENQUEUE_FAILED
 // (the enqueue thread's job failed) or an error (timeout).
 static const int32_t WAIT_RETRY = 1, WAIT_ENQUEUE_FAILED = 2;
