@@ -275,6 +275,11 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
         return keep ? (fp*)arena + (N - (N >> (r - 1))) : (fp*)(((r - 1) & 1) ? bufY : bufX);
     };
     if (keep) for (uint32_t r = 1; r < R; ++r) { keep->cws.push_back(cw_of(r)); keep->trees[r].lg = log_N - r; }
+    // With the c0 records on the card (ensure_chain) every kernel that needs a challenge waits for it itself — lane 0 of each workgroup
+    // polls the record's sequence word in local memory — and the k_wait_c0 launch in front of every round is gone (one launch boundary
+    // per round off the serial chain).  Records in pinned host memory keep the wait kernel: one poller, one PCIe read per poll.
+    static const bool wait_kernel = getenv("STARK_HIP_WAIT_KERNEL") != nullptr;              // A/B
+    const bool direct_wait = c->c0_buf != nullptr && c->c0_dev == c->c0_buf && !wait_kernel;
     uint32_t enq = 0;                              // rounds enqueued so far
     auto enqueue_round = [&]() -> int32_t {
         const uint32_t r = enq;
@@ -289,7 +294,7 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
             uint32_t target = 0;
             const bool roots_via_kernel = lg_tree <= 7 && blocks > 1 && d_roots;      // finished roots of several workgroups: to device memory, then k_publish_digests
             if (lg_tree <= 7 && blocks > 1 && !roots_via_kernel) { c->batch_done_total += (uint32_t)blocks; target = c->batch_done_total; }
-            const bool poll_inside = fold && B == 1 && blocks == 1;        // else a wait kernel first: exactly one workgroup ever polls host memory (round_kernels.hip)
+            const bool poll_inside = fold && (direct_wait || (B == 1 && blocks == 1));   // records in pinned host memory: a wait kernel first unless one workgroup is all there is
             if (fold && !poll_inside)
                 HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->c0_dev + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->c0_dev + lay.c0(r - 1)),
                                       (fp*)d_c0, B, d_abort, hd_abort, timeout_ticks, c->stream));
@@ -316,11 +321,17 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
             fp* next = cw_of(r);
             if (sh.small) SHCHK(small_round(true, in, next, ilog2(half)));
             else {
-                HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->c0_dev + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->c0_dev + lay.c0(r - 1)),
-                                      (fp*)d_c0, B, d_abort, hd_abort, timeout_ticks, c->stream));
                 const uint32_t K = sh.K;
                 digest64* dst = first ? first : c->d_root;
-                HIPCHK(launch_fold_leaf_subtree(in, L, B, (const fp*)d_c0, fp_zero(), tw_inv, log_N, r - 1, next, dst, K, c->stream, d_abort));
+                if (direct_wait) {                                 // the fold kernel waits itself and reads the constants out of the record
+                    const ChainWait cwt{reinterpret_cast<const uint32_t*>(c->c0_dev + lay.c0_seq(r - 1)), gen, d_abort, hd_abort, timeout_ticks};
+                    HIPCHK(launch_fold_leaf_subtree(in, L, B, reinterpret_cast<const fp*>(c->c0_dev + lay.c0(r - 1)), fp_zero(), tw_inv, log_N, r - 1, next, dst, K, c->stream, d_abort, 0,
+                                                    &cwt));
+                } else {
+                    HIPCHK(launch_wait_c0(reinterpret_cast<const uint32_t*>(c->c0_dev + lay.c0_seq(r - 1)), gen, reinterpret_cast<const fp*>(c->c0_dev + lay.c0(r - 1)),
+                                          (fp*)d_c0, B, d_abort, hd_abort, timeout_ticks, c->stream));
+                    HIPCHK(launch_fold_leaf_subtree(in, L, B, (const fp*)d_c0, fp_zero(), tw_inv, log_N, r - 1, next, dst, K, c->stream, d_abort));
+                }
                 SHCHK(enqueue_forest_reduce(c, dst, other, dst, ilog2(half) - K, B, rec, gen, d_abort, st, K, d_roots));
             }
         }

@@ -14,6 +14,7 @@
 // a single workgroup (k_merkle_tail).
 #include <stdlib.h>
 #include "kernels.h"
+#include "chain_wait.cuh"
 
 #define SUBTREE_KMAX 4
 #ifndef SUBTREE_WAVES
@@ -168,13 +169,15 @@ template <int KMAX>
 __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const fp* __restrict__ cw, uint32_t log_half, const fp* __restrict__ c0_arr,
                                                            fp c0_single, const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
                                                            fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out, uint32_t K,
-                                                           const uint32_t* __restrict__ d_abort, size_t w_base) {
+                                                           const uint32_t* __restrict__ d_abort, size_t w_base, const ChainWait wait) {
+    __shared__ uint32_t s_wait;
     if (d_abort && __hip_atomic_load(d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (wait.seq && !chain_wait_wg(wait, &s_wait, false)) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     const size_t j0 = i << K, half = (size_t)1 << log_half;
     const size_t b = j0 >> log_half, w0 = j0 & (half - 1);
-    const fp c0_mont = c0_arr ? c0_arr[b] : c0_single;
+    const fp c0_mont = c0_arr ? (wait.seq ? load_fp_sys(c0_arr + b) : c0_arr[b]) : c0_single;
     const fp* lo = cw + (b << (log_half + 1)) + w0;
     const fp* hi = lo + half;
     digest64 d = subtree_reduce<KMAX>(K, [&](uint32_t q) {
@@ -199,17 +202,19 @@ template <int K>
 __global__ __launch_bounds__(256, 2) void k_fold_leaf_subtree_staged(const fp* __restrict__ cw, uint32_t log_half, const fp* __restrict__ c0_arr, fp c0_single,
                                                                      const fp* __restrict__ tw_inv, uint32_t log_n_table, uint32_t tw_shift,
                                                                      fp* __restrict__ out, digest64* __restrict__ digests, size_t n_out,
-                                                                     const uint32_t* __restrict__ d_abort, size_t w_base) {
+                                                                     const uint32_t* __restrict__ d_abort, size_t w_base, const ChainWait wait) {
     constexpr uint32_t ROW = (1u << K) + 1, WAVE_ELEMS = 64 * ROW;
     __shared__ fp s_v[4 * WAVE_ELEMS];
+    __shared__ uint32_t s_wait;
     if (d_abort && __hip_atomic_load(d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (wait.seq && !chain_wait_wg(wait, &s_wait, false)) return;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // n_out is a multiple of 256: whole workgroups are in or out
     if (i >= n_out) return;
     const size_t half = (size_t)1 << log_half;
     const size_t wj0 = (i - lane) << K;                                        // first output of this wave
     const size_t b = wj0 >> log_half, ww0 = wj0 & (half - 1);
-    const fp c0_mont = c0_arr ? c0_arr[b] : c0_single;
+    const fp c0_mont = c0_arr ? (wait.seq ? load_fp_sys(c0_arr + b) : c0_arr[b]) : c0_single;
     const fp* lo = cw + (b << (log_half + 1)) + ww0;
     const fp* hi = lo + half;
     fp* mine = s_v + wave * WAVE_ELEMS;
@@ -298,23 +303,25 @@ hipError_t launch_fri_fold(const fp* lo, const fp* hi, size_t half, fp c0_mont, 
     return hipGetLastError();
 }
 hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* c0_arr, fp c0_single, const fp* tw_inv, uint32_t log_n_table,
-                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s, const uint32_t* d_abort, size_t w_base) {
+                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s, const uint32_t* d_abort, size_t w_base, const ChainWait* wait) {
     const size_t half = L / 2;
     if (!half || (half & (half - 1)) || !B || K > SUBTREE_KMAX || (half >> K) == 0) return hipErrorInvalidValue;
+    const ChainWait cwt = wait ? *wait : ChainWait{nullptr, 0, nullptr, nullptr, 0};
+    if (cwt.seq && (!c0_arr || !cwt.d_abort || !cwt.h_abort)) return hipErrorInvalidValue;
     uint32_t log_half = 0;
     while (((size_t)1 << log_half) < half) ++log_half;
     const size_t n_out = (B * half) >> K;
     static const bool no_stage = getenv("STARK_NO_STAGE") != nullptr;
     if (K >= 1 && K <= 3 && (n_out & 255) == 0 && log_half >= 6 + K && !no_stage) {          // whole 256-lane workgroups, waves inside one codeword
         const dim3 grid((unsigned)(n_out >> 8));
-        if (K == 3) hipLaunchKernelGGL(k_fold_leaf_subtree_staged<3>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort, w_base);
-        else if (K == 2) hipLaunchKernelGGL(k_fold_leaf_subtree_staged<2>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort, w_base);
-        else hipLaunchKernelGGL(k_fold_leaf_subtree_staged<1>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort, w_base);
+        if (K == 3) hipLaunchKernelGGL(k_fold_leaf_subtree_staged<3>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort, w_base, cwt);
+        else if (K == 2) hipLaunchKernelGGL(k_fold_leaf_subtree_staged<2>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort, w_base, cwt);
+        else hipLaunchKernelGGL(k_fold_leaf_subtree_staged<1>, grid, dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv, log_n_table, tw_shift, out, digests, n_out, d_abort, w_base, cwt);
         return hipGetLastError();
     }
     if (K <= 3) hipLaunchKernelGGL(k_fold_leaf_subtree<3>, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
-                                   log_n_table, tw_shift, out, digests, n_out, K, d_abort, w_base);
+                                   log_n_table, tw_shift, out, digests, n_out, K, d_abort, w_base, cwt);
     else hipLaunchKernelGGL(k_fold_leaf_subtree<4>, dim3(grid_for(n_out, 256)), dim3(256), 0, s, cw, log_half, c0_arr, c0_single, tw_inv,
-                            log_n_table, tw_shift, out, digests, n_out, K, d_abort, w_base);
+                            log_n_table, tw_shift, out, digests, n_out, K, d_abort, w_base, cwt);
     return hipGetLastError();
 }

@@ -112,12 +112,18 @@ hipError_t launch_quad_reduce(const digest64* in, digest64* out, size_t n_in, ui
 // round's codeword (a rank's slice of a sharded commit)
 hipError_t launch_fri_fold(const fp* lo, const fp* hi, size_t half, fp c0_mont, fp omega_inv, fp* out, hipStream_t s, const fp* c0_dev = nullptr, size_t i_base = 0,
                            const uint32_t* d_abort = nullptr);
+// A launch that waits for its round's challenge itself (chain_wait.cuh): lane 0 of every workgroup polls the sequence word of the
+// round's c0 record until it carries `gen` (bit 31: abort), for at most timeout_ticks of the 100 MHz clock; `d_abort` / `h_abort` as
+// launch_wait_c0.  seq == null: no wait.  Meant for records on the card (a poll of pinned host memory is a PCIe read).
+struct ChainWait { const uint32_t* seq; uint32_t gen; uint32_t* d_abort; uint32_t* h_abort; uint64_t timeout_ticks; };
 // fused round for B codewords of length L stored back to back: fold each into length L/2 (also back to back in
 // `out`) with twiddles w_N^-(i << tw_shift) from the inverse table of the top-level domain, and emit the 2^K-leaf
 // subtree digests of the folded codewords.  c0 = alpha/(2*offset) in Montgomery form: per codeword from the device
 // array `c0_arr`, or `c0_single` when c0_arr is null.
 hipError_t launch_fold_leaf_subtree(const fp* cw, size_t L, size_t B, const fp* c0_arr, fp c0_single, const fp* tw_inv, uint32_t log_n_table,
-                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s, const uint32_t* d_abort = nullptr, size_t w_base = 0);
+                                    uint32_t tw_shift, fp* out, digest64* digests, uint32_t K, hipStream_t s, const uint32_t* d_abort = nullptr, size_t w_base = 0,
+                                    const ChainWait* wait = nullptr);
+// wait: the kernel waits for the challenge itself and then takes c0_arr[b] out of the round's c0 record (c0_arr points into it)
 // w_base: global index of output 0 in the round's folded codeword (B == 1; a rank's slice of a sharded commit, whose lo | hi halves sit
 // back to back in `cw`): the twiddle of output w is w_N^-((w_base + w) << tw_shift)
 

@@ -11,27 +11,8 @@
 // wait kernels return at once.
 #include "kernels.h"
 #include "quad_b2b.cuh"
+#include "chain_wait.cuh"
 
-#define POLL_WORD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-// Post-mortem of a wait that ran out of spin, into the chain header (pinned host memory, 16 words): what was expected, what the
-// record held — read once more with the polling load, with a non-temporal load, and its neighbour word in the same 64-byte
-// line (the host never writes that one: it must read 0) —, where, how many polls, on which XCC, and the 100 MHz wall clock at
-// the start of the spin and now.  The host compares those two stamps with its own record of when it published (api_fri.hip).
-__device__ static void gave_up_record(uint32_t* h_abort, const uint32_t* h_seq, uint32_t gen, uint32_t where, uint32_t polls, uint64_t t0, bool round_wg) {
-    const uint64_t t1 = __builtin_amdgcn_s_memrealtime();
-    __hip_atomic_store(h_abort + 1, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(h_abort + 2, POLL_WORD(h_seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(h_abort + 3, (uint32_t)(reinterpret_cast<uintptr_t>(h_seq) - reinterpret_cast<uintptr_t>(h_abort)) | (round_wg ? 0x80000000u : 0u), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(h_abort + 4, where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(h_abort + 5, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(h_abort + 6, (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(h_abort + 7, __builtin_nontemporal_load(h_seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(h_abort + 8), t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(h_abort + 10), t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(h_abort + 14, POLL_WORD(h_seq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(h_abort, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 // the device's 100 MHz wall clock into pinned host memory: pairs it with the host's clock (debug runs only)
 __global__ void k_clock_probe(uint64_t* h_out) { __hip_atomic_store(h_out, (uint64_t)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 hipError_t launch_clock_probe(uint64_t* h_out, hipStream_t s) {
@@ -42,29 +23,8 @@ hipError_t launch_clock_probe(uint64_t* h_out, hipStream_t s) {
 __global__ __launch_bounds__(1024) void k_wait_c0(const uint32_t* __restrict__ h_seq, uint32_t gen, const fp* __restrict__ h_c0, fp* __restrict__ d_c0,
                                                   uint32_t B, uint32_t* __restrict__ d_abort, uint32_t* __restrict__ h_abort, uint64_t timeout_ticks) {
     __shared__ uint32_t s_state;
-    if (threadIdx.x == 0) {
-        uint32_t st = 0;
-        if (__hip_atomic_load(d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) st = 1;
-        else {
-            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-            uint32_t polls = 0;
-            for (;;) {
-                const uint32_t v = POLL_WORD(h_seq);
-                if ((v & 0x7fffffffu) == gen) { if (v >> 31) st = 1; break; }
-                if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) { st = 2; break; }
-                if ((++polls & 255u) == 0) __atomic_thread_fence(__ATOMIC_ACQUIRE);          // belt and braces: drop any cached copy of the record's line
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if (st) {
-                __hip_atomic_store(d_abort, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (st == 2) gave_up_record(h_abort, h_seq, gen, 1u << 16, polls, t0, false);
-            }
-        }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);                        // system scope: the c0 loads below come after the poll
-        s_state = st;
-    }
-    __syncthreads();
-    if (s_state) return;
+    const ChainWait w{h_seq, gen, d_abort, h_abort, timeout_ticks};
+    if (!chain_wait_wg(w, &s_state, false)) return;
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
         const uint64_t* src = reinterpret_cast<const uint64_t*>(h_c0 + b);
         const uint64_t lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -94,7 +54,7 @@ __global__ __launch_bounds__(256) void k_publish_digests(const digest64* __restr
 // goes to `sub_out` and k_quad_reduce finishes the <= 9 remaining levels.  FOLD = false is round 0: leaves = cw itself.
 struct RoundArgs {
     const fp* cw; fp* out;
-    uint32_t log_half, total;                  // outputs per codeword (log2); outputs over all codewords
+    uint32_t log_half, total, B;                // outputs per codeword (log2); outputs over all codewords
     const uint32_t* h_seq; uint32_t gen; const fp* h_c0; const fp* d_c0;   // h_seq != null: wait in the kernel (one codeword); else c0 = d_c0[b]
     uint32_t* d_abort; uint32_t* h_abort; uint64_t timeout_ticks;
     const fp* tw_inv; uint32_t log_n_table, tw_shift;
@@ -116,30 +76,11 @@ __global__ __launch_bounds__(RW_THREADS) void k_round_wg(const RoundArgs a) {
     // the level buffer at offset 0: 144 bytes, the value in words 0-1)
     if (tid >= 64 && tid < 112) s_sig[tid - 64] = (&QSIG[0][0])[tid - 64];
     for (uint32_t i = tid; i < RW_CHUNK * 16; i += RW_THREADS) sm[(i >> 4) * QR_PAIR_U64 + 2 + (i & 15)] = 0;
-    if (FOLD && a.h_seq) {
+    if (FOLD && a.h_seq) {                                                   // every workgroup waits for the challenge itself (chain_wait.cuh)
+        const ChainWait w{a.h_seq, a.gen, a.d_abort, a.h_abort, a.timeout_ticks};
         if (tid == 0) {
-            uint32_t st = 0;
-            if (__hip_atomic_load(a.d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) st = 1;
-            else {
-                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-                uint32_t polls = 0;
-                for (;;) {
-                    const uint32_t v = POLL_WORD(a.h_seq);
-                    if ((v & 0x7fffffffu) == a.gen) { if (v >> 31) st = 1; break; }
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { st = 2; break; }
-                    if ((++polls & 255u) == 0) __atomic_thread_fence(__ATOMIC_ACQUIRE);      // belt and braces: drop any cached copy of the record's line
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (st) {
-                    __hip_atomic_store(a.d_abort, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (st == 2) gave_up_record(a.h_abort, a.h_seq, a.gen, blockIdx.x | (gridDim.x << 16), polls, t0, true);
-                }
-            }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            if (!st) {                                                           // only this lane touches host memory: every such load is a PCIe round trip
-                const uint64_t* cs = reinterpret_cast<const uint64_t*>(a.h_c0);
-                s_c0 = fp_from_u64x2(__hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __hip_atomic_load(cs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-            }
+            const uint32_t st = chain_wait_poll(w, true);
+            if (!st && a.B == 1) s_c0 = load_fp_sys(a.h_c0);                     // one codeword: one lane fetches the constant
             s_state = st;
         }
         __syncthreads();
@@ -152,7 +93,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_round_wg(const RoundArgs a) {
         fp v;
         if (FOLD) {
             const uint32_t half = 1u << a.log_half, b = j >> a.log_half, w = j & (half - 1);
-            const fp c0 = a.h_seq ? s_c0 : a.d_c0[b];
+            const fp c0 = a.h_seq ? (a.B == 1 ? s_c0 : load_fp_sys(a.h_c0 + b)) : a.d_c0[b];
             const fp* lo = a.cw + ((size_t)b << (a.log_half + 1)) + w;
             fp tw = a.tw_inv[((size_t)w << a.tw_shift) & ((1u << NTT_TW_LO_BITS) - 1)];
             if (a.log_n_table > NTT_TW_LO_BITS) tw = mont_mul(tw, a.tw_inv[(1u << NTT_TW_LO_BITS) + (((size_t)w << a.tw_shift) >> NTT_TW_LO_BITS)]);
@@ -193,12 +134,11 @@ hipError_t launch_round_wg(bool fold, const fp* cw, fp* out, uint32_t log_half, 
     if (log_half > RW_CHUNK_LOG && !sub_out) return hipErrorInvalidValue;
     if (log_half <= RW_CHUNK_LOG && total > RW_CHUNK && !counter && !sub_out) return hipErrorInvalidValue;    // roots of several workgroups need one of the two ways out
     const unsigned blocks = (unsigned)((total + RW_CHUNK - 1) / RW_CHUNK);
-    // ONE poller only.  With lane 0 of 2-32 workgroups polling the same host line, one of them now and then kept reading the
-    // previous commit's value for the whole timeout (700k polls in a second, host memory already updated): measured, two contexts
-    // on one GPU, tests/test_gpu_parity.py::test_two_contexts_in_two_threads.  A single polling workgroup has never shown it.
-    if (fold && h_seq && (B != 1 || blocks != 1)) return hipErrorInvalidValue;
+    // h_seq: lane 0 of EVERY workgroup polls it.  Fine for a record on the card; for a record in pinned host memory every poll is a
+    // PCIe read, so the caller keeps that form to single-workgroup launches (api_fri.hip).
+    if (fold && h_seq && !h_c0) return hipErrorInvalidValue;
     if (fold && !h_seq && !d_c0) return hipErrorInvalidValue;
-    RoundArgs a{cw, out, log_half, (uint32_t)total, h_seq, gen, h_c0, d_c0, d_abort, h_abort, timeout_ticks, tw_inv, log_n_table, tw_shift, sub_out, rec_roots, rec_seq, counter, target};
+    RoundArgs a{cw, out, log_half, (uint32_t)total, (uint32_t)B, h_seq, gen, h_c0, d_c0, d_abort, h_abort, timeout_ticks, tw_inv, log_n_table, tw_shift, sub_out, rec_roots, rec_seq, counter, target};
     if (fold) hipLaunchKernelGGL(k_round_wg<true>, dim3(blocks), dim3(RW_THREADS), 0, s, a);
     else hipLaunchKernelGGL(k_round_wg<false>, dim3(blocks), dim3(RW_THREADS), 0, s, a);
     return hipGetLastError();
