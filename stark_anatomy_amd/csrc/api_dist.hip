@@ -443,8 +443,14 @@ static int32_t dist_fri_commit_impl(sh_dist* d, const fp* d_local, size_t N, con
                 digest64* dst = (digest64*)digA;
                 if (r == 0) HIPCHK(launch_leaf_subtree(d_local, dst, outs >> K, K, c->stream));
                 else {
-                    SHCHK(wait_c0(r - 1));
-                    HIPCHK(launch_fold_leaf_subtree(buf_of(r - 1), 2 * outs, 1, (const fp*)d_c0, fp_zero(), tw_inv, log_N, r - 1, chunk_of(r), dst, K, c->stream, d_abort, g * outs));
+                    if (c->c0_buf && c->c0_dev == c->c0_buf) {   // records on the card: the fold kernel waits itself (api_fri.hip, chain_wait.cuh)
+                        const ChainWait cwt{reinterpret_cast<const uint32_t*>(c->c0_dev + lay.c0_seq(r - 1)), gen, d_abort, hd_abort, timeout_ticks};
+                        HIPCHK(launch_fold_leaf_subtree(buf_of(r - 1), 2 * outs, 1, reinterpret_cast<const fp*>(c->c0_dev + lay.c0(r - 1)), fp_zero(), tw_inv, log_N, r - 1, chunk_of(r), dst,
+                                                        K, c->stream, d_abort, g * outs, &cwt));
+                    } else {
+                        SHCHK(wait_c0(r - 1));
+                        HIPCHK(launch_fold_leaf_subtree(buf_of(r - 1), 2 * outs, 1, (const fp*)d_c0, fp_zero(), tw_inv, log_N, r - 1, chunk_of(r), dst, K, c->stream, d_abort, g * outs));
+                    }
                 }
                 uint8_t* rec = c->d_chain + lay.roots(r);
                 if (P == 1) SHCHK(reduce_tree(c, dst, (digest64*)digB, dst, ilog2(outs) - K, nullptr, rec, gen, d_abort));
