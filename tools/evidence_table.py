@@ -125,14 +125,47 @@ def table(tag, log_n, B, title):
             f.write(f"| {k} | {calls[k]} | {dur[k] / 1e3:.1f} | {dur[k] / 1e3 / calls[k]:.1f} | {(f'{a / 1e6:.1f}' if a else '-')} | {cb / 1e6:.1f} | "
                     f"{(f'{a / t / 1e9:.0f}' if a else '-')} | {(f'{100 * a / t / HBM_PEAK:.1f}' if a else '-')} | {vb:.0f} | {vp:.0f} | "
                     f"{(100 * c.get('SQ_WAIT_INST_ANY', 0) / wc if wc else 0):.0f} | {(100 * c.get('SQ_WAIT_ANY', 0) / wc if wc else 0):.0f} |\n")
-        f.write(f"\nsum of kernel time without k_wait_c0: {sum(v for k, v in dur.items() if k != 'k_wait_c0') / 1e3:.1f} us.  k_wait_c0 (and a one-workgroup k_round_wg) "
-                "spends its time waiting for the host's challenge; under the profiler, in the first call of a process, the host side is many times slower "
-                "than in a timed run (there: 4.5-5.5 us per round, profiles/r02_commit_2p20_timeline.txt).\n")
+        f.write(f"\nsum of kernel time without k_wait_c0: {sum(v for k, v in dur.items() if k != 'k_wait_c0') / 1e3:.1f} us.  A single codeword's rounds have no k_wait_c0 "
+                "any more (late round 3): the first kernel of a round (k_fold_leaf_subtree*, k_round_wg) waits for the host's challenge itself, so its duration here includes "
+                "the host's turn — which under the profiler, in the first call of a process, is many times slower than in a timed run (there: ~4 us per round).  Batches "
+                "(w14x128) keep k_wait_c0.\n")
 
 
 b = one("bench/**/*kernel_stats.csv")
 if b:
     shutil.copy(b, os.path.join(PROF, f"{prefix}_bench_kernel_stats.csv"))
+bt = one("bench/**/*kernel_trace.csv")
+if bt:
+    # the roofline kernel of bench.py split by grid size, and the roofline leg's own back-to-back launches
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"])) for r in csv.DictReader(open(bt))), key=lambda r: r[0])
+    by = {}
+    for s0, e0, name, grid in rows:
+        if "k_leaf_subtree_staged<3>" in name:
+            by.setdefault(grid, []).append((e0 - s0) / 1e3)
+    best, run = [], []
+    for s0, e0, name, grid in rows:
+        if "k_leaf_subtree_staged<3>" in name and grid == 2097152:
+            run.append((e0 - s0) / 1e3)
+        else:
+            if len(run) > len(best):
+                best = run
+            run = []
+    if len(run) > len(best):
+        best = run
+    with open(os.path.join(PROF, f"{prefix}_bench_roofline_kernel_by_grid.csv"), "w") as f:
+        f.write(f"# {prefix}: k_leaf_subtree_staged<3> in the rocprofv3 --kernel-trace of `python3 bench.py --steps 5 --warmup 2 --no-cpu` (the run behind {prefix}_bench_kernel_stats.csv),\n"
+                "# split by grid size.  The --stats summary averages over every launch of the kernel name; bench.py launches it at several sizes (the 2^24 headline and\n"
+                "# roofline launches: 2^21 lanes; the 2 x 2^24 batch: 2^22 lanes; 2^20..2^22 commits; and one launch per 8 MiB chunk of the host-buffer commits), so the\n"
+                "# roofline launch (grid 2097152 threads = 2^24 leaves, K = 3) is listed on its own here: its average is what roofline.launch_ms is compared with\n"
+                "# (profiled runs clock lower than the event-timed launches of a plain run, MI355X_MICROARCH.md on DVFS).\n"
+                "grid_threads,calls,avg_us,min_us,max_us\n")
+        for grid in sorted(by):
+            v = by[grid]
+            f.write(f"{grid},{len(v)},{sum(v) / len(v):.1f},{min(v):.1f},{max(v):.1f}\n")
+        if best:
+            f.write(f"# the {len(best)} back-to-back launches of bench.py's roofline leg (sh_dev_merkle_subtrees, nothing else on the GPU): us each\n")
+            f.write("roofline_leg," + ",".join(f"{x:.1f}" for x in best) + "\n")
+            f.write(f"roofline_leg_avg_us,{sum(best) / len(best):.1f}\n")
 table("w24x1", 24, 1, "coset LDE 2^22 -> 2^24 + FRI commit 2^24")
 table("w20x1", 20, 1, "coset LDE 2^18 -> 2^20 + FRI commit 2^20")
 table("w14x128", 14, 128, "batched FRI commit 128 x 2^14")
