@@ -172,17 +172,31 @@ __global__ __launch_bounds__(256, SUBTREE_WAVES) void k_fold_leaf_subtree(const 
                                                            const uint32_t* __restrict__ d_abort, size_t w_base, const ChainWait wait) {
     __shared__ uint32_t s_wait;
     if (d_abort && __hip_atomic_load(d_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    if (wait.seq && !chain_wait_wg(wait, &s_wait, false)) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_out) return;
     const size_t j0 = i << K, half = (size_t)1 << log_half;
     const size_t b = j0 >> log_half, w0 = j0 & (half - 1);
-    const fp c0_mont = c0_arr ? (wait.seq ? load_fp_sys(c0_arr + b) : c0_arr[b]) : c0_single;
     const fp* lo = cw + (b << (log_half + 1)) + w0;
     const fp* hi = lo + half;
+    // a kernel that waits for the challenge itself takes its first output as far as it goes without it before the wait: the loads
+    // and (x + y)/2, (x - y)·w^-i are off the serial chain (exact arithmetic: the order of the two multiplies changes no bit)
+    fp pre_s = fp_zero(), pre_u = fp_zero();
+    if (wait.seq) {
+        if (i < n_out) {
+            const fp x = lo[0], y = hi[0];
+            pre_s = fp_half(fp_add(x, y));
+            pre_u = mont_mul(fp_sub(x, y), load_tw(tw_inv, log_n_table, (w_base + w0) << tw_shift));
+        }
+        if (!chain_wait_wg(wait, &s_wait, false)) return;
+    }
+    if (i >= n_out) return;
+    const fp c0_mont = c0_arr ? (wait.seq ? load_fp_sys(c0_arr + b) : c0_arr[b]) : c0_single;
     digest64 d = subtree_reduce<KMAX>(K, [&](uint32_t q) {
-        fp t = mont_mul(load_tw(tw_inv, log_n_table, (w_base + w0 + q) << tw_shift), c0_mont);
-        fp v = fold_one(lo[q], hi[q], t);
+        fp v;
+        if (wait.seq && q == 0) v = fp_add(pre_s, mont_mul(pre_u, c0_mont));
+        else {
+            fp t = mont_mul(load_tw(tw_inv, log_n_table, (w_base + w0 + q) << tw_shift), c0_mont);
+            v = fold_one(lo[q], hi[q], t);
+        }
         out[j0 + q] = v;
         return b2b_leaf(fp_lo64(v), fp_hi64(v));
     });

@@ -76,6 +76,19 @@ __global__ __launch_bounds__(RW_THREADS) void k_round_wg(const RoundArgs a) {
     // the level buffer at offset 0: 144 bytes, the value in words 0-1)
     if (tid >= 64 && tid < 112) s_sig[tid - 64] = (&QSIG[0][0])[tid - 64];
     for (uint32_t i = tid; i < RW_CHUNK * 16; i += RW_THREADS) sm[(i >> 4) * QR_PAIR_U64 + 2 + (i & 15)] = 0;
+    // Everything of the fold that does not need the challenge happens BEFORE the wait: the loads of the two inputs and of the twiddle
+    // (L2 / HBM latency), (x + y)/2 and (x - y)·w^-i.  out = (x + y)/2 + ((x - y)·w^-i)·c0 — exact modular arithmetic, so the order of the
+    // two multiplies does not change a bit of the result.
+    fp pre_s = fp_zero(), pre_u = fp_zero();
+    if (FOLD && tid < active) {
+        const uint32_t j = j0 + tid, half = 1u << a.log_half, b = j >> a.log_half, w = j & (half - 1);
+        const fp* lo = a.cw + ((size_t)b << (a.log_half + 1)) + w;
+        fp tw = a.tw_inv[((size_t)w << a.tw_shift) & ((1u << NTT_TW_LO_BITS) - 1)];
+        if (a.log_n_table > NTT_TW_LO_BITS) tw = mont_mul(tw, a.tw_inv[(1u << NTT_TW_LO_BITS) + (((size_t)w << a.tw_shift) >> NTT_TW_LO_BITS)]);
+        const fp x = lo[0], y = lo[half];
+        pre_s = fp_half(fp_add(x, y));
+        pre_u = mont_mul(fp_sub(x, y), tw);
+    }
     if (FOLD && a.h_seq) {                                                   // every workgroup waits for the challenge itself (chain_wait.cuh)
         const ChainWait w{a.h_seq, a.gen, a.d_abort, a.h_abort, a.timeout_ticks};
         if (tid == 0) {
@@ -92,13 +105,9 @@ __global__ __launch_bounds__(RW_THREADS) void k_round_wg(const RoundArgs a) {
         const uint32_t j = j0 + tid;
         fp v;
         if (FOLD) {
-            const uint32_t half = 1u << a.log_half, b = j >> a.log_half, w = j & (half - 1);
+            const uint32_t b = j >> a.log_half;
             const fp c0 = a.h_seq ? (a.B == 1 ? s_c0 : load_fp_sys(a.h_c0 + b)) : a.d_c0[b];
-            const fp* lo = a.cw + ((size_t)b << (a.log_half + 1)) + w;
-            fp tw = a.tw_inv[((size_t)w << a.tw_shift) & ((1u << NTT_TW_LO_BITS) - 1)];
-            if (a.log_n_table > NTT_TW_LO_BITS) tw = mont_mul(tw, a.tw_inv[(1u << NTT_TW_LO_BITS) + (((size_t)w << a.tw_shift) >> NTT_TW_LO_BITS)]);
-            const fp x = lo[0], y = lo[half];
-            v = fp_add(fp_half(fp_add(x, y)), mont_mul(fp_sub(x, y), mont_mul(tw, c0)));       // G4, as fold_one (hash_kernels.hip)
+            v = fp_add(pre_s, mont_mul(pre_u, c0));                                            // G4, as fold_one (hash_kernels.hip)
             a.out[j] = v;
         } else v = a.cw[j];
         sm[tid * QR_PAIR_U64] = fp_lo64(v);
