@@ -1,6 +1,7 @@
 // api_fri.hip — FRI drivers behind include/stark_hip.h: split-and-fold entry points, the commit loop (single codeword and
 // lock-step batches), the library-side transcript callback.
 #include "api_internal.h"
+#include <unistd.h>
 
 // ------------------------------------------------------------------ FRI
 int32_t check_params(const sh_fri_params* p, fp* offset) {
@@ -11,6 +12,15 @@ int32_t check_params(const sh_fri_params* p, fp* offset) {
     return SH_OK;
 }
 // ------------------------------------------------------------------ the commit chain (ChainLayout, ChainGuard: api_internal.h)
+// Is `p` mapped into this process?  Asked of the kernel (a pipe write from an unmapped address fails with EFAULT) rather than found out
+// by a store that would take the process down.
+static bool host_can_read(const void* p) {
+    int fd[2];
+    if (pipe(fd) != 0) return false;
+    const ssize_t n = write(fd[1], p, 4);
+    close(fd[0]); close(fd[1]);
+    return n == 4;
+}
 int32_t ensure_chain(sh_ctx* c, size_t bytes, size_t c0_end) {
     if (c->chain_bytes < bytes) {
         if (c->h_chain) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->h_chain)); c->h_chain = nullptr; c->d_chain = nullptr; c->chain_bytes = 0; }
@@ -33,7 +43,8 @@ int32_t ensure_chain(sh_ctx* c, size_t bytes, size_t c0_end) {
         if (hipExtMallocWithFlags((void**)&c->c0_buf, want, hipDeviceMallocUncached) == hipSuccess) {
             HIPCHK(hipMemsetAsync(c->c0_buf, 0, want, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
-            c->c0_bytes = want;
+            if (host_can_read(c->c0_buf)) c->c0_bytes = want;
+            else { (void)hipFree(c->c0_buf); c->c0_buf = nullptr; }     // the attribute promised a mapping that is not there: stay with pinned records
         } else { (void)hipGetLastError(); c->c0_buf = nullptr; }
     }
     if (large_bar && c->c0_buf) c->c0_host = c->c0_dev = c->c0_buf;
