@@ -58,7 +58,7 @@ struct NttPlan {
     uint32_t log_n;
     uint32_t num_passes;
     uint32_t bits[NTT_MAX_PASSES];           // radix bits per pass, sum == log_n; bits[0] is the most significant input digit
-    uint32_t tile_log;                       // elements per LDS tile (log2): 12, or 11 / 10 where 2^12 would leave most CUs without a tile
+    uint32_t tile_log[NTT_MAX_PASSES];       // per pass: elements per LDS tile (log2), 10..12 (ntt_make_plan)
 };
 // batch: transforms per launch (the tile size is chosen for batch · 2^log_n elements)
 void ntt_make_plan(uint32_t log_n, NttPlan* plan, size_t batch = 1);

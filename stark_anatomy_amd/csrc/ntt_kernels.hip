@@ -20,6 +20,7 @@
 // Since the last level group is a specialisation of its own (ntt_levels<S, true>) the kernel needs 60, and the asm form
 // wins: 0.95 -> 0.90 ms (-DFP_MONT_MUL_C brings the C form back).
 #include "kernels.h"
+#include <string.h>
 #ifdef NTT_TRACE
 #include <vector>
 #include <cstdio>
@@ -396,14 +397,26 @@ void ntt_make_plan(uint32_t log_n, NttPlan* plan, size_t batch) {
         plan->bits[i] = b;
         rem -= b;
     }
-    // Tile size.  2^12 elements (64 KiB, 1024 threads, two per CU) is the best shape when every CU has tiles to spare; a 2^18
+    // Tile size, per pass.  2^12 elements (64 KiB, 1024 threads, two per CU) is the best shape when every CU has tiles to spare; a 2^18
     // transform has only 64 of them.  Halve the tile (and its workgroup) while fewer than 1024 tiles exist, as long as its rows
     // stay >= 16 elements (256 bytes) long: 2^18 0.046 -> 0.030 ms (profiles/r03_ntt_phase_experiment.txt §6).
-    static const int forced = [] { const char* e = getenv("STARK_HIP_NTT_TILE_LOG"); return e ? atoi(e) : 0; }();
+    // STARK_HIP_NTT_TILE_LOG: one value for every pass, or a comma-separated value per pass (A/B runs).
     uint32_t tl = NTT_TILE_LOG;
     while (tl > 10 && tl - 1 >= plan->bits[0] + 4 && (((batch ? batch : 1) << log_n) >> tl) < 1024) --tl;
-    if (forced >= 10 && forced <= NTT_TILE_LOG && (uint32_t)forced >= plan->bits[0] + 2) tl = (uint32_t)forced;
-    plan->tile_log = tl;
+    // and no pass gets a tile wider than 16 columns x its rows: four 2^11 tiles per CU hide each other's waits better than two 2^12
+    // ones (2^22: 0.204 -> 0.196 ms), what a tile must keep is the 256-byte row
+    for (uint32_t i = 0; i < NTT_MAX_PASSES; ++i) plan->tile_log[i] = (i < P && plan->bits[i] + 4 < tl && plan->bits[i] + 4 >= 10) ? plan->bits[i] + 4 : tl;
+    if (const char* e = getenv("STARK_HIP_NTT_TILE_LOG")) {
+        uint32_t last = 0;
+        for (uint32_t i = 0; i < P; ++i) {
+            uint32_t v = (uint32_t)atoi(e);
+            if (v == 0) v = last;
+            last = v;
+            if (v >= 10 && v <= NTT_TILE_LOG && v >= plan->bits[i] + 2) plan->tile_log[i] = v;
+            const char* c = strchr(e, ',');
+            if (c) e = c + 1;
+        }
+    }
 }
 
 static size_t pass_lds_bytes(uint32_t log_r, uint32_t log_c, bool is_final) {
@@ -436,7 +449,7 @@ hipError_t launch_pow_table(fp* out, size_t count, fp base_mont, hipStream_t s) 
 bool ntt_lde_fusable(const NttPlan& plan, uint32_t log_expansion, NttLdeShape* shape) {
     if (plan.num_passes < 2 || log_expansion == 0 || log_expansion > plan.bits[0]) return false;
     const uint32_t log_r = plan.bits[0], log_mp = plan.log_n - log_r;
-    const uint32_t log_c = (plan.tile_log - log_r) < log_mp ? (plan.tile_log - log_r) : log_mp;
+    const uint32_t log_c = (plan.tile_log[0] - log_r) < log_mp ? (plan.tile_log[0] - log_r) : log_mp;
     shape->rows = (size_t)1 << (log_r - log_expansion);
     shape->chunks = (size_t)1 << (log_mp - log_c);
     shape->cols = (size_t)1 << log_c;
@@ -486,7 +499,7 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         if (!is_final) {
             p.log_m = log_n - consumed;
             const uint32_t log_mp = p.log_m - p.log_r;
-            p.log_c = (plan.tile_log - p.log_r) < log_mp ? (plan.tile_log - p.log_r) : log_mp;
+            p.log_c = (plan.tile_log[pi] - p.log_r) < log_mp ? (plan.tile_log[pi] - p.log_r) : log_mp;
             p.tw_pass = ptab ? ptab->t[pi] : nullptr;
             p.in = data;                                               // non-final passes work in place on `data` ...
             p.out = (pi + 2 == P) ? scratch : data;                    // ... except the last one, which lands in scratch
@@ -496,7 +509,7 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
             }
         } else {
             p.log_r0 = (P >= 2) ? plan.bits[0] : 0;
-            p.log_c = (plan.tile_log - p.log_r) < p.log_r0 ? (plan.tile_log - p.log_r) : p.log_r0;
+            p.log_c = (plan.tile_log[pi] - p.log_r) < p.log_r0 ? (plan.tile_log[pi] - p.log_r) : p.log_r0;
             p.num_mid = (P >= 2) ? P - 2 : 0;
             for (uint32_t q = 0; q < p.num_mid; ++q) p.mid_bits[q] = plan.bits[1 + q];
             p.apply_scale = apply_scale ? 1 : 0;
@@ -523,9 +536,9 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         if (tracing && !d_trace && hipMalloc(&d_trace, 8192 * 64) != hipSuccess) return hipErrorOutOfMemory;
         p.trace = tracing ? d_trace : nullptr;
         static const size_t lds_extra = getenv("STARK_HIP_NTT_LDS_EXTRA") ? (size_t)atoi(getenv("STARK_HIP_NTT_LDS_EXTRA")) : 0;    // e.g. 24576: one workgroup per CU
-        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS >> (NTT_TILE_LOG - plan.tile_log)), lds + lds_extra, s, p);
+        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS >> (NTT_TILE_LOG - plan.tile_log[pi])), lds + lds_extra, s, p);
 #else
-        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS >> (NTT_TILE_LOG - plan.tile_log)), lds, s, p);
+        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS >> (NTT_TILE_LOG - plan.tile_log[pi])), lds, s, p);
 #endif
 #ifdef NTT_TRACE
         if (tracing) {
