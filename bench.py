@@ -53,6 +53,66 @@ def random_elems(n, seed):
     return raw
 
 
+def dist_leg_main(args):
+    """Child process of one rank of `bench.py --gpus N` (N > 1): one 2^log_n transform and one commit spread over all ranks."""
+    import torch.distributed as dist
+    world = int(os.environ["WORLD_SIZE"])
+    rank = int(os.environ["RANK"])
+    local_rank = int(os.environ.get("STARK_BENCH_DIST_LOCAL_RANK", os.environ.get("LOCAL_RANK", "0")))
+    backend = os.environ.get("STARK_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    log_n = args.log_n
+    N = 1 << log_n
+    try:
+        from stark_anatomy_amd import dist_ntt as dn
+        eng = dn.GpuEngine(local_rank)
+        H = eng.ctx.handle
+        m = N // world
+        seed = np.frombuffer(np.random.default_rng(4242 + rank).bytes(16 * m), dtype=np.uint64).reshape(m, 2)
+        red = np.empty_like(seed)
+        _lib.check(_lib.lib.sh_fp_new(H, _u64p(np.ascontiguousarray(seed)), _u64p(red), m))
+        x = eng.from_host(red)
+        res = {}
+
+        def t_max(fn, reps):
+            fn()
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            torch.cuda.synchronize(); dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item()) / reps, r
+        t_ntt, X = t_max(lambda: dn.dist_ntt(x, log_n, eng), 3)
+        res[f"ntt_2^{log_n}_ms"] = 1e3 * t_ntt
+        res[f"ntt_2^{log_n}_GBps"] = 32.0 * N / t_ntt / 1e9
+        t_rows, _ = t_max(lambda: dn.dist_ntt(x, log_n, eng, output_layout="rows"), 3)
+        res[f"ntt_2^{log_n}_rows_layout_ms"] = 1e3 * t_rows
+        back = dn.dist_ntt(X, log_n, eng, inverse=True)
+        with eng.scope():
+            ok = bool(torch.equal(back, x))
+        t_fri, (roots, last, _ps) = t_max(lambda: dn.dist_fri_commit(X, N, eng, sa.GENERATOR, 4, 17), 2)
+        res[f"fri_commit_2^{log_n}_ms"] = 1e3 * t_fri
+        res[f"fri_commit_2^{log_n}_elems_per_s"] = N / t_fri
+        full = dn.all_gather_slices(X)
+        torch.cuda.synchronize()
+        r1, _l1 = sa.Fri(sa.GENERATOR, None, N, 4, 17, ctx=eng.ctx).commit(full, sa.ProofStream())
+        same = [h.as_bytes() for h in r1] == [bytes(a) for a in roots]
+        flag = torch.tensor([int(ok and same)], device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        res["round_trip_and_single_gpu_roots_match"] = bool(flag.item())
+        res["ranks"] = world
+    except Exception as e:  # reported, never fatal for the headline
+        res = {"error": f"{type(e).__name__}: {e}"[:300]}
+    print(json.dumps(res), flush=True)
+    os._exit(0)                                                                # no teardown of a communicator that may be wedged
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,7 +121,10 @@ def main():
     ap.add_argument("--log-n", type=int, default=24, help="log2 of the FRI domain (codeword length)")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dist-leg", action="store_true", help="internal: the child process of the N > 1 strong-scaling leg")
     args = ap.parse_args()
+    if args.dist_leg:
+        return dist_leg_main(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -328,69 +391,43 @@ def main():
     out["extra"] = extra
 
     # ---- N > 1 only: ONE 2^log_n transform / commit spread over all ranks (BASELINE config 5; strong scaling, RCCL
-    # all-to-all over xGMI).  Reported beside the headline, never as `value`.  Runs under a watchdog: if a collective
-    # stalls, the headline line is still printed and the process leaves.
+    # all-to-all over xGMI).  Reported beside the headline, never as `value`.  Runs in a CHILD process per rank (its own process
+    # group on its own port): a collective that stalls, or a crash inside the communication library, costs this leg only — the
+    # parent kills its own child at the time limit, reports the error in the line and still prints the headline.
     if world > 1 and not args.no_extra and os.environ.get("STARK_BENCH_DIST", "1") != "0":
-        import threading
-        box = {}
-
-        def dist_leg():
-            try:
-                torch.cuda.set_device(local_rank)
-                from stark_anatomy_amd import dist_ntt as dn
-                eng = dn.GpuEngine(local_rank)
-                m = N // world
-                seed = np.frombuffer(np.random.default_rng(4242 + rank).bytes(16 * m), dtype=np.uint64).reshape(m, 2)
-                red = np.empty_like(seed)
-                _lib.check(_lib.lib.sh_fp_new(H, _u64p(np.ascontiguousarray(seed)), _u64p(red), m))
-                x = eng.from_host(red)
-                res = {}
-
-                def t_max(fn, reps):
-                    fn()
-                    dist.barrier(); torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for _ in range(reps):
-                        r = fn()
-                    torch.cuda.synchronize(); dist.barrier()
-                    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    return float(t.item()) / reps, r
-                t_ntt, X = t_max(lambda: dn.dist_ntt(x, log_n, eng), 3)
-                res[f"ntt_2^{log_n}_ms"] = 1e3 * t_ntt
-                res[f"ntt_2^{log_n}_GBps"] = 32.0 * N / t_ntt / 1e9
-                t_rows, _ = t_max(lambda: dn.dist_ntt(x, log_n, eng, output_layout="rows"), 3)
-                res[f"ntt_2^{log_n}_rows_layout_ms"] = 1e3 * t_rows
-                back = dn.dist_ntt(X, log_n, eng, inverse=True)
-                with eng.scope():
-                    ok = bool(torch.equal(back, x))
-                t_fri, (roots, last, _ps) = t_max(lambda: dn.dist_fri_commit(X, N, eng, sa.GENERATOR, 4, 17), 2)
-                res[f"fri_commit_2^{log_n}_ms"] = 1e3 * t_fri
-                res[f"fri_commit_2^{log_n}_elems_per_s"] = N / t_fri
-                full = dn.all_gather_slices(X)
-                torch.cuda.synchronize()
-                r1, _l1 = sa.Fri(sa.GENERATOR, None, N, 4, 17, ctx=eng.ctx).commit(full, sa.ProofStream())
-                same = [h.as_bytes() for h in r1] == [bytes(a) for a in roots]
-                flag = torch.tensor([int(ok and same)], device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                res["round_trip_and_single_gpu_roots_match"] = bool(flag.item())
-                box["res"] = res
-            except Exception as e:  # reported, never fatal for the headline
-                box["res"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        th = threading.Thread(target=dist_leg, daemon=True)
-        th.start()
-        th.join(timeout=float(os.environ.get("STARK_BENCH_DIST_TIMEOUT", "120")))
-        if th.is_alive():
-            # the headline above is valid; the strong-scaling leg hung.  Every rank leaves with status 3 (no re-exec, no retry).
-            out["dist_error"] = "watchdog: distributed leg did not finish"
-            out["extra"]["dist_one_codeword_over_all_gpus"] = {"error": out["dist_error"]}
-            if rank == 0:
-                print(json.dumps(out), flush=True)
-            os._exit(3)
-        out["extra"]["dist_one_codeword_over_all_gpus"] = box.get("res")
-        if isinstance(box.get("res"), dict) and "error" in box["res"]:
-            out["dist_error"] = box["res"]["error"]
-        elif isinstance(box.get("res"), dict) and box["res"].get("round_trip_and_single_gpu_roots_match") is False:
+        import socket
+        import subprocess
+        port_t = torch.zeros(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        if rank == 0:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port_t[0] = sk.getsockname()[1]
+        dist.broadcast(port_t, 0)
+        env = dict(os.environ)
+        env["MASTER_PORT"] = str(int(port_t.item()))
+        env["STARK_BENCH_DIST_LOCAL_RANK"] = str(local_rank)
+        for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE"):      # the child makes a plain env:// rendezvous on its own port
+            env.pop(k, None)
+        limit = float(os.environ.get("STARK_BENCH_DIST_TIMEOUT", "150"))
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--dist-leg", "--log-n", str(log_n), "--gpus", str(world)],
+                                 env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            c_out, c_err = child.communicate(timeout=limit)
+            res = None
+            for line in reversed(c_out.splitlines()):
+                if line.startswith("{"):
+                    res = json.loads(line)
+                    break
+            if res is None:
+                res = {"error": f"distributed leg left with status {child.returncode}: {c_err.strip()[-300:]}"}
+        except subprocess.TimeoutExpired:
+            child.kill()                                                        # this rank's own child, by handle
+            child.communicate()
+            res = {"error": f"watchdog: distributed leg did not finish within {limit:.0f} s"}
+        out["extra"]["dist_one_codeword_over_all_gpus"] = res
+        if "error" in res:
+            out["dist_error"] = res["error"]
+        elif res.get("round_trip_and_single_gpu_roots_match") is False:
             out["dist_error"] = "distributed NTT round trip or distributed commit roots differ from the single-GPU result"
 
     if rank == 0 and world == 1 and not args.no_cpu:
