@@ -241,6 +241,105 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_EU) void k_ntt_pass(NttP
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// k_ntt_pass_reg — a non-final pass of 2^8 rows x 16 columns whose butterflies never go through LDS between level groups.
+// A wave's 64 lanes are (t: lane bits 5,4) x (c: the 16 columns, lane bits 3..0) and every lane holds four elements e, so a wave
+// holds 16 rows x 16 columns: FOUR row bits (two in e, two in t).  gfx950's v_permlane32_swap / v_permlane16_swap exchange
+// register halves between lanes that differ in lane bit 5 / bit 4 — one instruction per dword does the 2 x 2 transpose
+// "register bit <-> lane bit" — so after a radix-4 step over the register bits, 16 swaps bring the lane's row bits into the
+// registers and the next radix-4 step runs on them: four levels per wave with no memory in between.  The columns sit in the lane
+// bits the swaps never touch, so a wave's global loads and stores stay 256-byte rows and a level's twiddle is one LDS word per
+// 16 lanes, as in k_ntt_pass.
+//   phase 1: wave w holds rows (b7..b4 | w), loaded straight from HBM: levels 7,6 | swap | levels 5,4
+//   one trip through LDS (the only one; k_ntt_pass makes five): rows regrouped so that wave W holds rows (W | b3..b0)
+//   phase 2: levels 3,2 | swap | levels 1,0, then the inter-pass twiddle and the store, straight from registers.
+// Two workgroup barriers (after the w_R table, inside the LDS trip) instead of six; between them the waves run free.
+template <bool LO0>
+__device__ __forceinline__ void ntt_radix4(fp (&v)[4], const fp* __restrict__ twr, uint32_t r_low, uint32_t lo) {
+    // levels lo+1, lo of the 2^8-point DIF on v[e] = row (… | e << lo | r_low); as ntt_levels<2, LO0> with log_r = 8
+#pragma unroll
+    for (int s = 1; s >= 0; --s) {
+        const uint32_t sh = 7 - (lo + s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e & (1 << s)) continue;
+            const fp u = v[e], t = v[e | (1 << s)];
+            v[e] = fp_add(u, t);
+            fp d = fp_sub(u, t);
+            if (LO0 ? (e & ((1 << s) - 1)) != 0 : true) d = mont_mul(d, twr[(r_low + ((uint32_t)(e & ((1 << s) - 1)) << lo)) << sh]);
+            v[e | (1 << s)] = d;
+        }
+    }
+}
+// v[e] of lane t  <->  v[t] of lane e   (t = lane bits 5,4): element (e, t) of the 4 x 4 block that four lanes of one column hold
+__device__ __forceinline__ void ntt_swap_reg_lane(fp (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int e0 = 0; e0 < 2; ++e0) {                               // register bit 1 <-> lane bit 5
+            auto r = __builtin_amdgcn_permlane32_swap(v[e0].w[i], v[e0 | 2].w[i], false, false);
+            v[e0].w[i] = r[0]; v[e0 | 2].w[i] = r[1];
+        }
+#pragma unroll
+        for (int e1 = 0; e1 < 4; e1 += 2) {                            // register bit 0 <-> lane bit 4
+            auto r = __builtin_amdgcn_permlane16_swap(v[e1].w[i], v[e1 | 1].w[i], false, false);
+            v[e1].w[i] = r[0]; v[e1 | 1].w[i] = r[1];
+        }
+    }
+}
+__global__ __launch_bounds__(1024, 8) void k_ntt_pass_reg(NttPassParams p) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    fp* x = reinterpret_cast<fp*>(lds_raw);                       // 256 rows x 16 columns
+    fp* twr = x + 4096;                                           // w_256^e, e < 128 (Montgomery form)
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, t = (tid >> 4) & 3, c = tid & 15;
+    const size_t tile = blockIdx.x & ((1u << p.log_tiles) - 1);
+    const size_t xform = (size_t)(blockIdx.x >> p.log_tiles) << p.log_n;
+    const fp* __restrict__ in = p.in + (p.fuse_log_e ? xform >> p.fuse_log_e : xform);
+    fp* __restrict__ out = p.out + xform;
+    const uint32_t log_mp = p.log_m - 8;
+    const size_t chunks = (size_t)1 << (log_mp - 4);
+    const size_t block = tile / chunks, chunk = tile % chunks;
+    const uint32_t colbase = (uint32_t)(chunk << 4);
+    const size_t base = (block << p.log_m) + colbase + c, row_stride = (size_t)1 << log_mp;
+
+    fp v[4];
+    const uint32_t r_n = 256u >> p.fuse_log_e;                    // fused LDE: rows from r_n on are zero padding
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t r = ((uint32_t)e << 6) | (t << 4) | wave;
+        v[e] = r < r_n ? in[base + (size_t)r * row_stride] : fp_zero();
+    }
+    if (tid < 128) twr[tid] = ntt_load_tw(p.tw, p.log_n, (size_t)tid << (p.log_n - 8));
+    if (p.fuse_log_e) {                                           // coefficient j = r·row_stride + colbase + c takes offset^j
+        const fp pcc = mont_mul(p.pow_chunk[chunk], p.pow_col[c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t r = ((uint32_t)e << 6) | (t << 4) | wave;
+            if (r < r_n) v[e] = mont_mul(v[e], mont_mul(p.pow_row[r], pcc));
+        }
+    }
+    __syncthreads();
+    ntt_radix4<false>(v, twr, (t << 4) | wave, 6);
+    ntt_swap_reg_lane(v);                                         // now v[e] = row (t << 6 | e << 4 | wave)
+    ntt_radix4<false>(v, twr, wave, 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[(((t << 6) | ((uint32_t)e << 4) | wave) << 4) + c] = v[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = x[(((wave << 4) | ((uint32_t)e << 2) | t) << 4) + c];
+    ntt_radix4<false>(v, twr, t, 2);
+    ntt_swap_reg_lane(v);                                         // now v[e] = row (wave << 4 | t << 2 | e)
+    ntt_radix4<true>(v, twr, 0, 0);
+    const uint32_t tw_shift = p.log_n - p.log_m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t r = (wave << 4) | (t << 2) | (uint32_t)e;
+        const uint32_t k = __brev(r) >> 24;
+        const fp w = p.tw_pass ? p.tw_pass[(size_t)k * row_stride + colbase + c] : ntt_load_tw(p.tw, p.log_n, ((size_t)(colbase + c) * k) << tw_shift);
+        out[base + (size_t)k * row_stride] = mont_mul(v[e], w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_ntt_pass_pipe — the same pass as a PERSISTENT workgroup with the next tile's loads in flight during this tile's levels.
 // Why: with the butterflies taken out, the three passes of a 2^24 transform still take 0.30 ms (the tile fills and drains: 5.4 TB/s),
 // with them 0.86 ms — the kernel above runs its memory phases and its arithmetic one after the other, and two workgroups per CU do
@@ -483,6 +582,8 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
     const uint32_t P = plan.num_passes, log_n = plan.log_n;
@@ -526,7 +627,10 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         const char* pipe_env = getenv("STARK_HIP_NTT_PIPE");
         const int pipe_mode = pipe_env ? atoi(pipe_env) : 0;
         static const unsigned pipe_wgs = [] { const char* e = getenv("STARK_HIP_NTT_PIPE_WGS"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 256); }();
-        if (pipe_mode && (p.log_r + p.log_c) == NTT_TILE_LOG && tiles >= 4 * (size_t)pipe_wgs) {
+        static const int reg_mode = [] { const char* e = getenv("STARK_HIP_NTT_REG"); return e ? atoi(e) : 1; }();
+        if (reg_mode && !is_final && p.log_r == 8 && p.log_c == 4) {
+            hipLaunchKernelGGL(k_ntt_pass_reg, dim3((unsigned)tiles), dim3(1024), (4096 + 128) * sizeof(fp), s, p);
+        } else if (pipe_mode && (p.log_r + p.log_c) == NTT_TILE_LOG && tiles >= 4 * (size_t)pipe_wgs) {
             hipLaunchKernelGGL(k_ntt_pass_pipe, dim3(pipe_wgs), dim3(NTT_THREADS), lds, s, p, (uint32_t)tiles);
         } else {
 #ifdef NTT_TRACE
