@@ -286,56 +286,126 @@ __device__ __forceinline__ void ntt_swap_reg_lane(fp (&v)[4]) {
         }
     }
 }
+// FINAL: the pass over the contiguous digit.  Its rows arrive as 4 KiB runs along r, so the tile takes one extra trip through LDS
+// (padded rows, as in k_ntt_pass) to turn the lanes from "along r" to "along the 16 columns"; from there on the same two phases,
+// and the digit-reversing scatter to natural order goes out of the registers in 256-byte runs.  ZPAD: first pass of a coset LDE
+// with expansion 4 — rows 64.. are zero padding, so levels 7 and 6 are three multiplies per lane and no add or subtract.
+template <bool FINAL>
 __global__ __launch_bounds__(1024, 8) void k_ntt_pass_reg(NttPassParams p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    fp* x = reinterpret_cast<fp*>(lds_raw);                       // 256 rows x 16 columns
-    fp* twr = x + 4096;                                           // w_256^e, e < 128 (Montgomery form)
+    fp* x = reinterpret_cast<fp*>(lds_raw);                       // 256 rows x 16 columns (row stride 17 in the final pass)
+    constexpr uint32_t RS = FINAL ? 17 : 16;
+    fp* twr = x + 256 * RS;                                       // w_256^e, e < 128 (Montgomery form)
     const uint32_t tid = threadIdx.x, wave = tid >> 6, t = (tid >> 4) & 3, c = tid & 15;
     const size_t tile = blockIdx.x & ((1u << p.log_tiles) - 1);
     const size_t xform = (size_t)(blockIdx.x >> p.log_tiles) << p.log_n;
     const fp* __restrict__ in = p.in + (p.fuse_log_e ? xform >> p.fuse_log_e : xform);
     fp* __restrict__ out = p.out + xform;
-    const uint32_t log_mp = p.log_m - 8;
-    const size_t chunks = (size_t)1 << (log_mp - 4);
-    const size_t block = tile / chunks, chunk = tile % chunks;
-    const uint32_t colbase = (uint32_t)(chunk << 4);
-    const size_t base = (block << p.log_m) + colbase + c, row_stride = (size_t)1 << log_mp;
-
     fp v[4];
-    const uint32_t r_n = 256u >> p.fuse_log_e;                    // fused LDE: rows from r_n on are zero padding
+    size_t base = 0, row_stride = 0, chunk = 0;
+    uint32_t colbase = 0;
+    bool zpad = false;
+    if (!FINAL) {
+        const uint32_t log_mp = p.log_m - 8;
+        const size_t chunks = (size_t)1 << (log_mp - 4);
+        const size_t block = tile / chunks;
+        chunk = tile % chunks;
+        colbase = (uint32_t)(chunk << 4);
+        base = (block << p.log_m) + colbase + c;
+        row_stride = (size_t)1 << log_mp;
+        const uint32_t r_n = 256u >> p.fuse_log_e;                // fused LDE: rows from r_n on are zero padding
+        zpad = p.fuse_log_e == 2;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const uint32_t r = ((uint32_t)e << 6) | (t << 4) | wave;
-        v[e] = r < r_n ? in[base + (size_t)r * row_stride] : fp_zero();
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t r = ((uint32_t)e << 6) | (t << 4) | wave;
+            v[e] = r < r_n ? in[base + (size_t)r * row_stride] : fp_zero();
+        }
+    } else {
+        const size_t chunks = (size_t)1 << (p.log_r0 - 4);        // chunks of digit-0 values
+        const size_t mid = tile / chunks;
+        chunk = tile % chunks;
+        colbase = (uint32_t)(chunk << 4);
+        base = mid << 8;
+        row_stride = (size_t)1 << (p.log_n - p.log_r0);           // stride of digit 0 in the in-place layout
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t idx = tid + q * 1024, cc = idx >> 8, r = idx & 255;
+            v[q] = in[(size_t)(colbase + cc) * row_stride + base + r];
+        }
     }
     if (tid < 128) twr[tid] = ntt_load_tw(p.tw, p.log_n, (size_t)tid << (p.log_n - 8));
-    if (p.fuse_log_e) {                                           // coefficient j = r·row_stride + colbase + c takes offset^j
+    if (!FINAL && p.fuse_log_e) {                                 // coefficient j = r·row_stride + colbase + c takes offset^j
         const fp pcc = mont_mul(p.pow_chunk[chunk], p.pow_col[c]);
+        const uint32_t r_n = 256u >> p.fuse_log_e;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t r = ((uint32_t)e << 6) | (t << 4) | wave;
             if (r < r_n) v[e] = mont_mul(v[e], mont_mul(p.pow_row[r], pcc));
         }
     }
+    if (FINAL) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t idx = tid + q * 1024, cc = idx >> 8, r = idx & 255;
+            x[r * RS + cc] = v[q];
+        }
+    }
     __syncthreads();
-    ntt_radix4<false>(v, twr, (t << 4) | wave, 6);
+    if (FINAL) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = x[(((uint32_t)e << 6) | (t << 4) | wave) * RS + c];
+    }
+    if (zpad) {                                                   // v[1..3] == 0: out = (a, a·w^(2j), a·w^j, a·w^(3j)), j = row mod 64
+        const uint32_t j = (t << 4) | wave;
+        v[2] = mont_mul(v[0], twr[j]);
+        v[1] = mont_mul(v[0], twr[j << 1]);
+        v[3] = mont_mul(v[2], twr[j << 1]);
+    } else {
+        ntt_radix4<false>(v, twr, (t << 4) | wave, 6);
+    }
     ntt_swap_reg_lane(v);                                         // now v[e] = row (t << 6 | e << 4 | wave)
     ntt_radix4<false>(v, twr, wave, 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) x[(((t << 6) | ((uint32_t)e << 4) | wave) << 4) + c] = v[e];
+    for (int e = 0; e < 4; ++e) x[((t << 6) | ((uint32_t)e << 4) | wave) * RS + c] = v[e];    // the rows this wave read: no barrier before
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = x[(((wave << 4) | ((uint32_t)e << 2) | t) << 4) + c];
+    for (int e = 0; e < 4; ++e) v[e] = x[((wave << 4) | ((uint32_t)e << 2) | t) * RS + c];
     ntt_radix4<false>(v, twr, t, 2);
     ntt_swap_reg_lane(v);                                         // now v[e] = row (wave << 4 | t << 2 | e)
     ntt_radix4<true>(v, twr, 0, 0);
-    const uint32_t tw_shift = p.log_n - p.log_m;
+    if (!FINAL) {
+        const uint32_t tw_shift = p.log_n - p.log_m;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const uint32_t r = (wave << 4) | (t << 2) | (uint32_t)e;
-        const uint32_t k = __brev(r) >> 24;
-        const fp w = p.tw_pass ? p.tw_pass[(size_t)k * row_stride + colbase + c] : ntt_load_tw(p.tw, p.log_n, ((size_t)(colbase + c) * k) << tw_shift);
-        out[base + (size_t)k * row_stride] = mont_mul(v[e], w);
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t r = (wave << 4) | (t << 2) | (uint32_t)e;
+            const uint32_t k = __brev(r) >> 24;
+            const fp w = p.tw_pass ? p.tw_pass[(size_t)k * row_stride + colbase + c] : ntt_load_tw(p.tw, p.log_n, ((size_t)(colbase + c) * k) << tw_shift);
+            out[base + (size_t)k * row_stride] = mont_mul(v[e], w);
+        }
+    } else {
+        // out index = k_0 + R_0·(midrev + M·k_last)
+        const size_t chunks = (size_t)1 << (p.log_r0 - 4);
+        size_t mid = tile / chunks, midrev = 0;
+        uint32_t log_M = 0;
+        for (int q = (int)p.num_mid - 1; q >= 0; --q) log_M += p.mid_bits[q];
+        {
+            uint32_t sh = 0;
+            size_t rem = mid;
+            for (int q = (int)p.num_mid - 1; q >= 0; --q) {
+                const size_t dq = rem & (((size_t)1 << p.mid_bits[q]) - 1);
+                rem >>= p.mid_bits[q];
+                sh += p.mid_bits[q];
+                midrev |= dq << (log_M - sh);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t r = (wave << 4) | (t << 2) | (uint32_t)e;
+            const uint32_t k = __brev(r) >> 24;
+            fp o = v[e];
+            if (p.apply_scale) o = mont_mul(o, p.scale);
+            out[(size_t)(colbase + c) + ((((size_t)k << log_M) + midrev) << p.log_r0)] = o;
+        }
     }
 }
 
@@ -582,7 +652,9 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_reg<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_reg<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
@@ -627,9 +699,13 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         const char* pipe_env = getenv("STARK_HIP_NTT_PIPE");
         const int pipe_mode = pipe_env ? atoi(pipe_env) : 0;
         static const unsigned pipe_wgs = [] { const char* e = getenv("STARK_HIP_NTT_PIPE_WGS"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 256); }();
-        static const int reg_mode = [] { const char* e = getenv("STARK_HIP_NTT_REG"); return e ? atoi(e) : 1; }();
-        if (reg_mode && !is_final && p.log_r == 8 && p.log_c == 4) {
-            hipLaunchKernelGGL(k_ntt_pass_reg, dim3((unsigned)tiles), dim3(1024), (4096 + 128) * sizeof(fp), s, p);
+        // STARK_HIP_NTT_REG (read per call, A/B and tests): bit 0 = register-exchange form for non-final 2^8-row passes, bit 1 = for the final pass
+        const char* reg_env = getenv("STARK_HIP_NTT_REG");
+        const int reg_mode = reg_env ? atoi(reg_env) : 3;
+        if ((reg_mode & 1) && !is_final && p.log_r == 8 && p.log_c == 4) {
+            hipLaunchKernelGGL(k_ntt_pass_reg<false>, dim3((unsigned)tiles), dim3(1024), (256 * 16 + 128) * sizeof(fp), s, p);
+        } else if ((reg_mode & 2) && is_final && P >= 2 && p.log_r == 8 && p.log_c == 4) {
+            hipLaunchKernelGGL(k_ntt_pass_reg<true>, dim3((unsigned)tiles), dim3(1024), (256 * 17 + 128) * sizeof(fp), s, p);
         } else if (pipe_mode && (p.log_r + p.log_c) == NTT_TILE_LOG && tiles >= 4 * (size_t)pipe_wgs) {
             hipLaunchKernelGGL(k_ntt_pass_pipe, dim3(pipe_wgs), dim3(NTT_THREADS), lds, s, p, (uint32_t)tiles);
         } else {

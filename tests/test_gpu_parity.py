@@ -411,6 +411,45 @@ def test_ntt_pipelined_pass_matches(ctx, monkeypatch):
     assert np.array_equal(sa.coset_lde(x[: 1 << 20], 2, G, ctx=ctx), ref_lde)
 
 
+@pytest.mark.parametrize("log_n", [16, 17, 22, 24])
+def test_ntt_register_exchange_pass_matches_lds_pass(ctx, monkeypatch, log_n):
+    """2^8-row passes run in the register-exchange form by default (ntt_kernels.hip: k_ntt_pass_reg — levels through
+    v_permlane32/16_swap, one LDS trip); STARK_HIP_NTT_REG=0 selects the LDS form (k_ntt_pass) for every pass.  Same bits for
+    the forward and inverse transform (with its 1/n scale), a batch, and the fused coset LDE (zero-padding specialisation of
+    levels 7 and 6); the default form is compared with the oracle at 2^16 and 2^17 here and in the all-sizes test."""
+    n = 1 << log_n
+    x = co.splitmix_elems(900 + log_n, n)
+    d = ctx.alloc(n * 16)
+    d_c = ctx.alloc((n >> 2) * 16).upload(np.ascontiguousarray(x[: n >> 2]))
+
+    def run_all():
+        outs = []
+        for inv in (False, True):
+            d.upload(x); sa.dev_ntt(ctx, d, log_n, inverse=inv)
+            outs.append(d.download(np.uint64, (n, 2)))
+        sa.dev_coset_lde(ctx, d_c, log_n - 2, 2, G, d)
+        outs.append(d.download(np.uint64, (n, 2)))
+        if log_n == 16:                                              # a batch of three 2^14 -> 2^16 extensions: the tile index carries the transform index
+            d_c3 = ctx.alloc(3 * (n >> 2) * 16).upload(np.ascontiguousarray(x[: 3 * (n >> 2)]))
+            d_b = ctx.alloc(3 * n * 16)
+            sa.dev_coset_lde_batch(ctx, d_c3, 3, log_n - 2, 2, G, d_b)
+            outs.append(d_b.download(np.uint64, (3 * n, 2)))
+            d_c3.free(); d_b.free()
+        return outs
+    new = run_all()
+    monkeypatch.setenv("STARK_HIP_NTT_REG", "0")
+    old = run_all()
+    for a, b in zip(new, old):
+        assert np.array_equal(a, b)
+    monkeypatch.setenv("STARK_HIP_NTT_REG", "1")                      # non-final passes only
+    for a, b in zip(run_all(), old):
+        assert np.array_equal(a, b)
+    if log_n <= 17:
+        assert np.array_equal(new[0], co.ntt(x))
+        assert np.array_equal(new[2], co.coset_lde(np.ascontiguousarray(x[: n >> 2]), 2, G))
+    d.free(); d_c.free()
+
+
 # ------------------------------------------------------------------ batched commits (BASELINE config 4)
 @pytest.mark.parametrize("B,log_n", [(1, 10), (3, 7), (8, 14), (128, 14), (5, 1), (2, 18), (8, 19), (8, 20), (3, 22), (4, 22)])
 def test_fri_commit_batch_vs_oracle(ctx, B, log_n):
