@@ -94,8 +94,9 @@ static int32_t fail_gave_up(sh_ctx* c, uint32_t round, uint32_t gen, uint32_t re
 // full workgroups (2^9 digests) while there is work, balanced launches once it is latency only.
 uint32_t forest_step(uint32_t lg, size_t B, bool* quad) {
     const size_t total = B << lg;
-    if (total > ((size_t)1 << QUAD_MAX_LOG_COUNT)) {
-        const uint32_t over = ilog2(total) - QUAD_MAX_LOG_COUNT;
+    static const uint32_t quad_max = [] { const char* e = getenv("STARK_HIP_QUAD_MAX_LOG"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 10 && v <= 22 ? v : QUAD_MAX_LOG_COUNT); }();
+    if (total > ((size_t)1 << quad_max)) {
+        const uint32_t over = ilog2(total) - quad_max;
         uint32_t step = over < 3 ? over : 3;
         *quad = false;
         return step > lg ? lg : step;

@@ -241,24 +241,30 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_EU) void k_ntt_pass(NttP
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_ntt_pass_reg — a non-final pass of 2^8 rows x 16 columns whose butterflies never go through LDS between level groups.
+// k_ntt_pass_reg — a pass of R = 2^LR rows (LR = 6, 7, 8) x 16 columns whose butterflies never go through LDS between level groups.
 // A wave's 64 lanes are (t: lane bits 5,4) x (c: the 16 columns, lane bits 3..0) and every lane holds four elements e, so a wave
 // holds 16 rows x 16 columns: FOUR row bits (two in e, two in t).  gfx950's v_permlane32_swap / v_permlane16_swap exchange
 // register halves between lanes that differ in lane bit 5 / bit 4 — one instruction per dword does the 2 x 2 transpose
-// "register bit <-> lane bit" — so after a radix-4 step over the register bits, 16 swaps bring the lane's row bits into the
-// registers and the next radix-4 step runs on them: four levels per wave with no memory in between.  The columns sit in the lane
-// bits the swaps never touch, so a wave's global loads and stores stay 256-byte rows and a level's twiddle is one LDS word per
-// 16 lanes, as in k_ntt_pass.
-//   phase 1: wave w holds rows (b7..b4 | w), loaded straight from HBM: levels 7,6 | swap | levels 5,4
-//   one trip through LDS (the only one; k_ntt_pass makes five): rows regrouped so that wave W holds rows (W | b3..b0)
-//   phase 2: levels 3,2 | swap | levels 1,0, then the inter-pass twiddle and the store, straight from registers.
-// Two workgroup barriers (after the w_R table, inside the LDS trip) instead of six; between them the waves run free.
-template <bool LO0>
+// "register bit <-> lane bit" (tools/permlane_probe.hip prints the lane maps) — so after a radix-4 step over the register bits,
+// 16 swaps bring the lane's row bits into the registers and the next radix-4 step runs on them: four levels per wave with no
+// memory in between.  The columns sit in the lane bits the swaps never touch, so a wave's global loads and stores stay 256-byte
+// rows and a level's twiddle is one LDS word per 16 lanes, as in k_ntt_pass.
+//   phase 1: wave w holds rows (top four bits | w), loaded straight from HBM: levels LR-1, LR-2 | swap | levels LR-3, LR-4
+//   one trip through LDS (the only one; k_ntt_pass makes five): rows regrouped so that wave W holds rows (W | low bits)
+//   phase 2: the LR-4 low levels — LR = 8: 3,2 | swap | 1,0;  LR = 7: 2,1 | half swap | 0;  LR = 6: 1,0 — then the inter-pass
+//   twiddle and the store, straight from registers.
+// Two workgroup barriers (after the w_R table, inside the LDS trip) instead of six; between them the waves run free: VALUBusy
+// 87-94 % against 73 % (profiles/r03_ntt_register_exchange.txt).
+// FINAL: the pass over the contiguous digit.  Its rows arrive as runs along r, so the tile takes one extra trip through LDS
+// (padded rows, as in k_ntt_pass) to turn the lanes from "along r" to "along the 16 columns"; from there on the same two phases,
+// and the digit-reversing scatter to natural order goes out of the registers in 256-byte runs.  Fused coset LDE with expansion
+// 4 (zpad): rows R/4.. are zero padding, so the top two levels are three multiplies per lane and no add or subtract.
+template <int LR, bool LO0>
 __device__ __forceinline__ void ntt_radix4(fp (&v)[4], const fp* __restrict__ twr, uint32_t r_low, uint32_t lo) {
-    // levels lo+1, lo of the 2^8-point DIF on v[e] = row (… | e << lo | r_low); as ntt_levels<2, LO0> with log_r = 8
+    // levels lo+1, lo of the 2^LR-point DIF on v[e] = row (… | e << lo | r_low); as ntt_levels<2, LO0> with log_r = LR
 #pragma unroll
     for (int s = 1; s >= 0; --s) {
-        const uint32_t sh = 7 - (lo + s);
+        const uint32_t sh = LR - 1 - (lo + s);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (e & (1 << s)) continue;
@@ -270,54 +276,59 @@ __device__ __forceinline__ void ntt_radix4(fp (&v)[4], const fp* __restrict__ tw
         }
     }
 }
-// v[e] of lane t  <->  v[t] of lane e   (t = lane bits 5,4): element (e, t) of the 4 x 4 block that four lanes of one column hold
-__device__ __forceinline__ void ntt_swap_reg_lane(fp (&v)[4]) {
+// register bit 1 <-> lane bit 5
+__device__ __forceinline__ void ntt_swap_hi(fp (&v)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int e0 = 0; e0 < 2; ++e0) {                               // register bit 1 <-> lane bit 5
+        for (int e0 = 0; e0 < 2; ++e0) {
             auto r = __builtin_amdgcn_permlane32_swap(v[e0].w[i], v[e0 | 2].w[i], false, false);
             v[e0].w[i] = r[0]; v[e0 | 2].w[i] = r[1];
         }
+}
+// register bit 0 <-> lane bit 4
+__device__ __forceinline__ void ntt_swap_lo(fp (&v)[4]) {
 #pragma unroll
-        for (int e1 = 0; e1 < 4; e1 += 2) {                            // register bit 0 <-> lane bit 4
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e1 = 0; e1 < 4; e1 += 2) {
             auto r = __builtin_amdgcn_permlane16_swap(v[e1].w[i], v[e1 | 1].w[i], false, false);
             v[e1].w[i] = r[0]; v[e1 | 1].w[i] = r[1];
         }
-    }
 }
-// FINAL: the pass over the contiguous digit.  Its rows arrive as 4 KiB runs along r, so the tile takes one extra trip through LDS
-// (padded rows, as in k_ntt_pass) to turn the lanes from "along r" to "along the 16 columns"; from there on the same two phases,
-// and the digit-reversing scatter to natural order goes out of the registers in 256-byte runs.  ZPAD: first pass of a coset LDE
-// with expansion 4 — rows 64.. are zero padding, so levels 7 and 6 are three multiplies per lane and no add or subtract.
-template <bool FINAL>
-__global__ __launch_bounds__(1024, 8) void k_ntt_pass_reg(NttPassParams p) {
+// v[e] of lane t  <->  v[t] of lane e   (t = lane bits 5,4): the 4 x 4 block that four lanes of one column hold, transposed
+__device__ __forceinline__ void ntt_swap_reg_lane(fp (&v)[4]) { ntt_swap_hi(v); ntt_swap_lo(v); }
+
+template <int LR, bool FINAL, bool FUSE, bool DIRECT_TW>      // FUSE: first pass of a fused coset LDE; DIRECT_TW: the pass has a direct table of its inter-pass twiddles
+__global__ __launch_bounds__(4 << LR, 8) void k_ntt_pass_reg(NttPassParams p) {
+    static_assert(LR >= 6 && LR <= 8, "rows");
+    constexpr uint32_t R = 1u << LR, NT = 4u << LR, L2 = LR - 4;  // L2: row bits of the second phase = log2(waves)
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    fp* x = reinterpret_cast<fp*>(lds_raw);                       // 256 rows x 16 columns (row stride 17 in the final pass)
+    fp* x = reinterpret_cast<fp*>(lds_raw);                       // R rows x 16 columns (row stride 17 in the final pass)
     constexpr uint32_t RS = FINAL ? 17 : 16;
-    fp* twr = x + 256 * RS;                                       // w_256^e, e < 128 (Montgomery form)
+    fp* twr = x + R * RS;                                         // w_R^e, e < R/2 (Montgomery form)
     const uint32_t tid = threadIdx.x, wave = tid >> 6, t = (tid >> 4) & 3, c = tid & 15;
     const size_t tile = blockIdx.x & ((1u << p.log_tiles) - 1);
     const size_t xform = (size_t)(blockIdx.x >> p.log_tiles) << p.log_n;
-    const fp* __restrict__ in = p.in + (p.fuse_log_e ? xform >> p.fuse_log_e : xform);
+    const fp* __restrict__ in = p.in + (FUSE ? xform >> p.fuse_log_e : xform);
     fp* __restrict__ out = p.out + xform;
     fp v[4];
     size_t base = 0, row_stride = 0, chunk = 0;
     uint32_t colbase = 0;
     bool zpad = false;
     if (!FINAL) {
-        const uint32_t log_mp = p.log_m - 8;
+        const uint32_t log_mp = p.log_m - LR;
         const size_t chunks = (size_t)1 << (log_mp - 4);
         const size_t block = tile / chunks;
         chunk = tile % chunks;
         colbase = (uint32_t)(chunk << 4);
         base = (block << p.log_m) + colbase + c;
         row_stride = (size_t)1 << log_mp;
-        const uint32_t r_n = 256u >> p.fuse_log_e;                // fused LDE: rows from r_n on are zero padding
-        zpad = p.fuse_log_e == 2;
+        const uint32_t r_n = FUSE ? R >> p.fuse_log_e : R;        // fused LDE: rows from r_n on are zero padding
+        zpad = FUSE && p.fuse_log_e == 2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t r = ((uint32_t)e << 6) | (t << 4) | wave;
+            const uint32_t r = ((uint32_t)e << (LR - 2)) | (t << L2) | wave;
             v[e] = r < r_n ? in[base + (size_t)r * row_stride] : fp_zero();
         }
     } else {
@@ -325,61 +336,83 @@ __global__ __launch_bounds__(1024, 8) void k_ntt_pass_reg(NttPassParams p) {
         const size_t mid = tile / chunks;
         chunk = tile % chunks;
         colbase = (uint32_t)(chunk << 4);
-        base = mid << 8;
+        base = mid << LR;
         row_stride = (size_t)1 << (p.log_n - p.log_r0);           // stride of digit 0 in the in-place layout
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t idx = tid + q * 1024, cc = idx >> 8, r = idx & 255;
+            const uint32_t idx = tid + q * NT, cc = idx >> LR, r = idx & (R - 1);
             v[q] = in[(size_t)(colbase + cc) * row_stride + base + r];
         }
     }
-    if (tid < 128) twr[tid] = ntt_load_tw(p.tw, p.log_n, (size_t)tid << (p.log_n - 8));
-    if (!FINAL && p.fuse_log_e) {                                 // coefficient j = r·row_stride + colbase + c takes offset^j
+    if (tid < R / 2) twr[tid] = ntt_load_tw(p.tw, p.log_n, (size_t)tid << (p.log_n - LR));
+    if (!FINAL && FUSE) {                                         // coefficient j = r·row_stride + colbase + c takes offset^j
         const fp pcc = mont_mul(p.pow_chunk[chunk], p.pow_col[c]);
-        const uint32_t r_n = 256u >> p.fuse_log_e;
+        const uint32_t r_n = R >> p.fuse_log_e;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t r = ((uint32_t)e << 6) | (t << 4) | wave;
+            const uint32_t r = ((uint32_t)e << (LR - 2)) | (t << L2) | wave;
             if (r < r_n) v[e] = mont_mul(v[e], mont_mul(p.pow_row[r], pcc));
         }
     }
     if (FINAL) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t idx = tid + q * 1024, cc = idx >> 8, r = idx & 255;
+            const uint32_t idx = tid + q * NT, cc = idx >> LR, r = idx & (R - 1);
             x[r * RS + cc] = v[q];
         }
     }
     __syncthreads();
     if (FINAL) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = x[(((uint32_t)e << 6) | (t << 4) | wave) * RS + c];
+        for (int e = 0; e < 4; ++e) v[e] = x[(((uint32_t)e << (LR - 2)) | (t << L2) | wave) * RS + c];
     }
-    if (zpad) {                                                   // v[1..3] == 0: out = (a, a·w^(2j), a·w^j, a·w^(3j)), j = row mod 64
-        const uint32_t j = (t << 4) | wave;
+    // ---- phase 1: row = e << (LR-2) | t << L2 | wave
+    if (zpad) {                                                   // v[1..3] == 0: out = (a, a·w^(2j), a·w^j, a·w^(3j)), j = row mod R/4
+        const uint32_t j = (t << L2) | wave;
         v[2] = mont_mul(v[0], twr[j]);
         v[1] = mont_mul(v[0], twr[j << 1]);
         v[3] = mont_mul(v[2], twr[j << 1]);
     } else {
-        ntt_radix4<false>(v, twr, (t << 4) | wave, 6);
+        ntt_radix4<LR, false>(v, twr, (t << L2) | wave, LR - 2);
     }
-    ntt_swap_reg_lane(v);                                         // now v[e] = row (t << 6 | e << 4 | wave)
-    ntt_radix4<false>(v, twr, wave, 4);
+    ntt_swap_reg_lane(v);                                         // now v[e] = row (t << (LR-2) | e << L2 | wave)
+    ntt_radix4<LR, false>(v, twr, wave, L2);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) x[((t << 6) | ((uint32_t)e << 4) | wave) * RS + c] = v[e];    // the rows this wave read: no barrier before
+    for (int e = 0; e < 4; ++e) x[((t << (LR - 2)) | ((uint32_t)e << L2) | wave) * RS + c] = v[e];    // the rows this wave read: no barrier before
     __syncthreads();
+    // ---- phase 2: wave W holds rows W << 4 | (16 rows): the low L2 bits and, for L2 < 4, 4 - L2 of the bits phase 1 has finished
+    uint32_t rows[4];                                             // row of v[e] when the levels are done
+    if (LR == 8) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = x[((wave << 4) | ((uint32_t)e << 2) | t) * RS + c];
-    ntt_radix4<false>(v, twr, t, 2);
-    ntt_swap_reg_lane(v);                                         // now v[e] = row (wave << 4 | t << 2 | e)
-    ntt_radix4<true>(v, twr, 0, 0);
+        for (int e = 0; e < 4; ++e) v[e] = x[((wave << 4) | ((uint32_t)e << 2) | t) * RS + c];
+        ntt_radix4<LR, false>(v, twr, t, 2);
+        ntt_swap_reg_lane(v);
+        ntt_radix4<LR, true>(v, twr, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rows[e] = (wave << 4) | (t << 2) | (uint32_t)e;
+    } else if (LR == 7) {                                         // e = (b2, b1), lane bit 4 = b0, lane bit 5 = b3
+        const uint32_t b0 = t & 1, b3 = t >> 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = x[((wave << 4) | (b3 << 3) | ((uint32_t)e << 1) | b0) * RS + c];
+        ntt_radix4<LR, false>(v, twr, b0, 1);
+        ntt_swap_lo(v);                                           // now register bit 0 = b0, lane bit 4 = b1
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) { const fp u = v[e], w = v[e | 1]; v[e] = fp_add(u, w); v[e | 1] = fp_sub(u, w); }   // level 0: no twiddle
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rows[e] = (wave << 4) | (b3 << 3) | ((uint32_t)(e >> 1) << 2) | (b0 << 1) | (uint32_t)(e & 1);   // lane bit 4 now holds b1
+    } else {                                                      // LR == 6: e = (b1, b0), t = (b3, b2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = x[((wave << 4) | (t << 2) | (uint32_t)e) * RS + c];
+        ntt_radix4<LR, true>(v, twr, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rows[e] = (wave << 4) | (t << 2) | (uint32_t)e;
+    }
     if (!FINAL) {
         const uint32_t tw_shift = p.log_n - p.log_m;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t r = (wave << 4) | (t << 2) | (uint32_t)e;
-            const uint32_t k = __brev(r) >> 24;
-            const fp w = p.tw_pass ? p.tw_pass[(size_t)k * row_stride + colbase + c] : ntt_load_tw(p.tw, p.log_n, ((size_t)(colbase + c) * k) << tw_shift);
+            const uint32_t k = __brev(rows[e]) >> (32 - LR);
+            const fp w = DIRECT_TW ? p.tw_pass[(size_t)k * row_stride + colbase + c] : ntt_load_tw(p.tw, p.log_n, ((size_t)(colbase + c) * k) << tw_shift);
             out[base + (size_t)k * row_stride] = mont_mul(v[e], w);
         }
     } else {
@@ -400,13 +433,37 @@ __global__ __launch_bounds__(1024, 8) void k_ntt_pass_reg(NttPassParams p) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t r = (wave << 4) | (t << 2) | (uint32_t)e;
-            const uint32_t k = __brev(r) >> 24;
+            const uint32_t k = __brev(rows[e]) >> (32 - LR);
             fp o = v[e];
             if (p.apply_scale) o = mont_mul(o, p.scale);
             out[(size_t)(colbase + c) + ((((size_t)k << log_M) + midrev) << p.log_r0)] = o;
         }
     }
+}
+template <int LR>
+static hipError_t launch_pass_reg(const NttPassParams& p, size_t tiles, hipStream_t s) {
+    const dim3 g((unsigned)tiles), b(4u << LR);
+    static bool attr_set[64] = {};             // per device: the attribute belongs to the function on the current device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (LR == 8 && !attr_set[dev]) {           // only the 2^8-row tiles need more than the default 64 KiB
+        const void* regs[] = {reinterpret_cast<const void*>(k_ntt_pass_reg<LR, false, false, false>), reinterpret_cast<const void*>(k_ntt_pass_reg<LR, false, false, true>),
+                              reinterpret_cast<const void*>(k_ntt_pass_reg<LR, false, true, false>), reinterpret_cast<const void*>(k_ntt_pass_reg<LR, false, true, true>),
+                              reinterpret_cast<const void*>(k_ntt_pass_reg<LR, true, false, false>)};
+        for (const void* f : regs) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        attr_set[dev] = true;
+    }
+    const size_t R = (size_t)1 << LR;
+    if (p.is_final) hipLaunchKernelGGL((k_ntt_pass_reg<LR, true, false, false>), g, b, (R * 17 + R / 2) * sizeof(fp), s, p);
+    else {
+        const size_t l = (R * 16 + R / 2) * sizeof(fp);
+        if (p.fuse_log_e) { if (p.tw_pass) hipLaunchKernelGGL((k_ntt_pass_reg<LR, false, true, true>), g, b, l, s, p); else hipLaunchKernelGGL((k_ntt_pass_reg<LR, false, true, false>), g, b, l, s, p); }
+        else { if (p.tw_pass) hipLaunchKernelGGL((k_ntt_pass_reg<LR, false, false, true>), g, b, l, s, p); else hipLaunchKernelGGL((k_ntt_pass_reg<LR, false, false, false>), g, b, l, s, p); }
+    }
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -652,10 +709,6 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_reg<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_reg<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
     const uint32_t P = plan.num_passes, log_n = plan.log_n;
@@ -699,13 +752,14 @@ hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, 
         const char* pipe_env = getenv("STARK_HIP_NTT_PIPE");
         const int pipe_mode = pipe_env ? atoi(pipe_env) : 0;
         static const unsigned pipe_wgs = [] { const char* e = getenv("STARK_HIP_NTT_PIPE_WGS"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 256); }();
-        // STARK_HIP_NTT_REG (read per call, A/B and tests): bit 0 = register-exchange form for non-final 2^8-row passes, bit 1 = for the final pass
+        // STARK_HIP_NTT_REG (read per call, A/B and tests): bit 0 = register-exchange form for non-final passes, bit 1 = for the final pass, bit 2 = for 2^6- and 2^7-row passes too
         const char* reg_env = getenv("STARK_HIP_NTT_REG");
-        const int reg_mode = reg_env ? atoi(reg_env) : 3;
-        if ((reg_mode & 1) && !is_final && p.log_r == 8 && p.log_c == 4) {
-            hipLaunchKernelGGL(k_ntt_pass_reg<false>, dim3((unsigned)tiles), dim3(1024), (256 * 16 + 128) * sizeof(fp), s, p);
-        } else if ((reg_mode & 2) && is_final && P >= 2 && p.log_r == 8 && p.log_c == 4) {
-            hipLaunchKernelGGL(k_ntt_pass_reg<true>, dim3((unsigned)tiles), dim3(1024), (256 * 17 + 128) * sizeof(fp), s, p);
+        const int reg_mode = reg_env ? atoi(reg_env) : 7;
+        // register-exchange form: 2^6 .. 2^8 rows x 16 columns
+        const bool reg_shape = p.log_r >= 6 && p.log_r <= 8 && p.log_c == 4 && (p.log_r == 8 || (reg_mode & 4));
+        if (reg_shape && (is_final ? ((reg_mode & 2) && P >= 2) : (reg_mode & 1) != 0)) {
+            const hipError_t e = p.log_r == 8 ? launch_pass_reg<8>(p, tiles, s) : p.log_r == 7 ? launch_pass_reg<7>(p, tiles, s) : launch_pass_reg<6>(p, tiles, s);
+            if (e != hipSuccess) return e;
         } else if (pipe_mode && (p.log_r + p.log_c) == NTT_TILE_LOG && tiles >= 4 * (size_t)pipe_wgs) {
             hipLaunchKernelGGL(k_ntt_pass_pipe, dim3(pipe_wgs), dim3(NTT_THREADS), lds, s, p, (uint32_t)tiles);
         } else {

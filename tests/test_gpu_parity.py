@@ -411,10 +411,11 @@ def test_ntt_pipelined_pass_matches(ctx, monkeypatch):
     assert np.array_equal(sa.coset_lde(x[: 1 << 20], 2, G, ctx=ctx), ref_lde)
 
 
-@pytest.mark.parametrize("log_n", [16, 17, 22, 24])
+@pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
 def test_ntt_register_exchange_pass_matches_lds_pass(ctx, monkeypatch, log_n):
-    """2^8-row passes run in the register-exchange form by default (ntt_kernels.hip: k_ntt_pass_reg — levels through
-    v_permlane32/16_swap, one LDS trip); STARK_HIP_NTT_REG=0 selects the LDS form (k_ntt_pass) for every pass.  Same bits for
+    """Passes of 2^6, 2^7 and 2^8 rows x 16 columns run in the register-exchange form by default (ntt_kernels.hip: k_ntt_pass_reg —
+    levels through v_permlane32/16_swap, one LDS trip); STARK_HIP_NTT_REG=0 selects the LDS form (k_ntt_pass) for every pass; 3 keeps
+    the register form to 2^8 rows.  The sizes walk through every mix of pass widths (2^12 = 6+6 … 2^24 = 8+8+8).  Same bits for
     the forward and inverse transform (with its 1/n scale), a batch, and the fused coset LDE (zero-padding specialisation of
     levels 7 and 6); the default form is compared with the oracle at 2^16 and 2^17 here and in the all-sizes test."""
     n = 1 << log_n
@@ -441,9 +442,10 @@ def test_ntt_register_exchange_pass_matches_lds_pass(ctx, monkeypatch, log_n):
     old = run_all()
     for a, b in zip(new, old):
         assert np.array_equal(a, b)
-    monkeypatch.setenv("STARK_HIP_NTT_REG", "1")                      # non-final passes only
-    for a, b in zip(run_all(), old):
-        assert np.array_equal(a, b)
+    for mode in ("1", "3", "5", "6"):                                 # non-final passes only / 2^8 rows only / non-final of any width / final of any width
+        monkeypatch.setenv("STARK_HIP_NTT_REG", mode)
+        for a, b in zip(run_all(), old):
+            assert np.array_equal(a, b)
     if log_n <= 17:
         assert np.array_equal(new[0], co.ntt(x))
         assert np.array_equal(new[2], co.coset_lde(np.ascontiguousarray(x[: n >> 2]), 2, G))
