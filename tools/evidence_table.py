@@ -65,6 +65,7 @@ def workload_alg(log_n, B):
         N = 1 << log_n
         alg["k_coset_scale_pad"] += 16 * (N >> 2) + 16 * N
         alg["k_ntt_pass"] = -32 * N                    # per call: multiplied by the call count below
+        alg["k_ntt_pass_reg"] = -32 * N                # the register-exchange form of the same pass (all template instances under one name)
     return alg
 
 
