@@ -212,7 +212,7 @@ static int32_t fri_commit_core(sh_ctx* c, const fp* d_cws, size_t B, size_t N, c
     auto shape_of = [&](uint32_t r) {
         RoundShape sh;
         sh.lg_tree = log_N - r;
-        sh.small = use_round_wg && (B << sh.lg_tree) <= ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL) && sh.lg_tree >= 1;
+        sh.small = use_round_wg && (B << sh.lg_tree) <= ((size_t)1 << round_wg_max_log()) && sh.lg_tree >= 1;
         sh.K = sh.small ? (sh.lg_tree < 7 ? sh.lg_tree : 7) : leaf_k((size_t)1 << sh.lg_tree);
         sh.first = sh.K < sh.lg_tree ? (B << sh.lg_tree) >> sh.K : 0;
         return sh;
@@ -549,7 +549,7 @@ static int32_t upload_codeword_hashing(sh_ctx* c, const uint64_t* host, size_t N
     uint32_t K = leaf_subtree_k(lg);
     if (K > lg) K = lg;
     static const bool use_round_wg = getenv("STARK_NO_ROUND_WG") == nullptr;
-    const bool small = use_round_wg && N <= ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL) && lg >= 1;      // the fused one-launch round hashes its own leaves
+    const bool small = use_round_wg && N <= ((size_t)1 << round_wg_max_log()) && lg >= 1;      // the fused one-launch round hashes its own leaves
     void* dig = nullptr;
     const bool can = !small && K < lg && (N * sizeof(fp)) >= ((size_t)1 << 20);
     if (can) SHCHK(ensure_scratch(c, SCR_DIG_A, (N >> K) * sizeof(digest64), &dig));

@@ -155,7 +155,7 @@ FP_HD fp mont_mul_c(fp a, fp b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(FP_MONT_MUL_C)
 __device__ __forceinline__ uint32_t fp_addc(uint32_t x, uint32_t y, uint32_t cin, uint32_t* cout) { return __builtin_addc(x, y, cin, cout); }
 __device__ __forceinline__ uint32_t fp_subc(uint32_t x, uint32_t y, uint32_t bin, uint32_t* bout) { return __builtin_subc(x, y, bin, bout); }
-__device__ __forceinline__ fp mont_mul_dev(fp a, fp b) {
+__device__ __forceinline__ fp mont_mul_dev_eo(fp a, fp b) {
     // One asm statement per row a_i·b: its carries are made and used inside it, its accumulators go in and out as operands,
     // so the compiler is free to retire a_i and finished columns between rows (one 25-instruction block held 27 registers
     // at once and cost the NTT kernels three waves of occupancy).
@@ -238,6 +238,81 @@ __device__ __forceinline__ fp mont_mul_dev(fp a, fp b) {
     r0 = fp_addc(r0, m & 1u, 0, &cy); r1 = fp_addc(r1, 0, cy, &cy); r2 = fp_addc(r2, 0, cy, &cy); r3 = r3 + (m & FP_P3) + cy;
     return fp_make(r0, r1, r2, r3);
 }
+// Round 3, late: the product by PRODUCT SCANNING.  One 64-bit accumulator walks the seven columns of the 4 x 4 limb product; a
+// column's overflow bits (the multiply-add's own carry-out, one v_addc each) are counted straight into the word that becomes the
+// accumulator's high half for the next column, so handing a column over costs one full-rate v_mov (the old high word into the
+// low half of the next even-aligned pair) where the even/odd-column form above merges its seven accumulators with twelve
+// half-rate carry-chain adds.  The reduction folds its carry bit into the subtraction's borrow-in and the final "+p" takes the
+// borrow as carry-in (p's limb 0 is 1).  61 VALU instructions, 6 of them full-rate (71, none); bit-equal (tools/mm_bench.hip).
+// Carries never cross asm statements; inside one, two instructions or an s_nop sit between a carry's write and its read.
+#ifndef FP_MONT_MUL_EO
+#define FP_MM_COL2(acc, cc, x0, y0, x1, y1)                                                             \
+    asm("v_mad_u64_u32 %[A], vcc, %[X0], %[Y0], %[A]\n\t"                                             \
+        "v_mad_u64_u32 %[A], %[C1], %[X1], %[Y1], %[A]\n\t"                                           \
+        "s_nop 1\n\t"                                                                                 \
+        "v_addc_co_u32_e64 %[CC], vcc, 0, 0, %[C1]\n\t"                                               \
+        : [A] "+v"(acc), [CC] "=&v"(cc), [C1] "=&s"(c1)                                               \
+        : [X0] "v"(x0), [Y0] "v"(y0), [X1] "v"(x1), [Y1] "v"(y1) : "vcc")
+#define FP_MM_COL3(acc, cc, x0, y0, x1, y1, x2, y2)                                                     \
+    asm("v_mad_u64_u32 %[A], vcc, %[X0], %[Y0], %[A]\n\t"                                             \
+        "v_mad_u64_u32 %[A], %[C1], %[X1], %[Y1], %[A]\n\t"                                           \
+        "v_mad_u64_u32 %[A], %[C2], %[X2], %[Y2], %[A]\n\t"                                           \
+        "s_nop 0\n\t"                                                                                 \
+        "v_addc_co_u32_e64 %[CC], vcc, 0, 0, %[C1]\n\t"                                               \
+        "v_addc_co_u32_e64 %[CC], vcc, 0, %[CC], %[C2]\n\t"                                           \
+        : [A] "+v"(acc), [CC] "=&v"(cc), [C1] "=&s"(c1), [C2] "=&s"(c2)                               \
+        : [X0] "v"(x0), [Y0] "v"(y0), [X1] "v"(x1), [Y1] "v"(y1), [X2] "v"(x2), [Y2] "v"(y2) : "vcc")
+#define FP_MM_COL4(acc, cc, x0, y0, x1, y1, x2, y2, x3, y3)                                             \
+    asm("v_mad_u64_u32 %[A], vcc, %[X0], %[Y0], %[A]\n\t"                                             \
+        "v_mad_u64_u32 %[A], %[C1], %[X1], %[Y1], %[A]\n\t"                                           \
+        "v_mad_u64_u32 %[A], %[C2], %[X2], %[Y2], %[A]\n\t"                                           \
+        "v_mad_u64_u32 %[A], %[C3], %[X3], %[Y3], %[A]\n\t"                                           \
+        "v_addc_co_u32_e64 %[CC], vcc, 0, 0, %[C1]\n\t"                                               \
+        "v_addc_co_u32_e64 %[CC], vcc, 0, %[CC], %[C2]\n\t"                                           \
+        "v_addc_co_u32_e64 %[CC], vcc, 0, %[CC], %[C3]\n\t"                                           \
+        : [A] "+v"(acc), [CC] "=&v"(cc), [C1] "=&s"(c1), [C2] "=&s"(c2), [C3] "=&s"(c3)               \
+        : [X0] "v"(x0), [Y0] "v"(y0), [X1] "v"(x1), [Y1] "v"(y1), [X2] "v"(x2), [Y2] "v"(y2), [X3] "v"(x3), [Y3] "v"(y3) : "vcc")
+__device__ __forceinline__ uint64_t fp_mm_next(uint64_t acc, uint32_t cc) { return (acc >> 32) | ((uint64_t)cc << 32); }
+__device__ __forceinline__ fp mont_mul_dev(fp a, fp b) {
+    uint64_t c1, c2, c3, acc;
+    uint32_t cc, t0, t1, t2, t3, t4, t5, t6, t7;
+    acc = (uint64_t)a.w[0] * b.w[0];
+    t0 = (uint32_t)acc; acc >>= 32;
+    FP_MM_COL2(acc, cc, a.w[0], b.w[1], a.w[1], b.w[0]);
+    t1 = (uint32_t)acc; acc = fp_mm_next(acc, cc);
+    FP_MM_COL3(acc, cc, a.w[0], b.w[2], a.w[1], b.w[1], a.w[2], b.w[0]);
+    t2 = (uint32_t)acc; acc = fp_mm_next(acc, cc);
+    FP_MM_COL4(acc, cc, a.w[0], b.w[3], a.w[1], b.w[2], a.w[2], b.w[1], a.w[3], b.w[0]);
+    t3 = (uint32_t)acc; acc = fp_mm_next(acc, cc);
+    FP_MM_COL3(acc, cc, a.w[1], b.w[3], a.w[2], b.w[2], a.w[3], b.w[1]);
+    t4 = (uint32_t)acc; acc = fp_mm_next(acc, cc);
+    FP_MM_COL2(acc, cc, a.w[2], b.w[3], a.w[3], b.w[2]);
+    t5 = (uint32_t)acc; acc = fp_mm_next(acc, cc);
+    acc = (uint64_t)a.w[3] * b.w[3] + acc;                       // < 2^64: the whole product is
+    t6 = (uint32_t)acc; t7 = (uint32_t)(acc >> 32);
+    // reduction as before
+    uint32_t cy;
+    const uint64_t x0 = (uint64_t)t0 * 407u;
+    const uint32_t k9 = (uint32_t)x0 & 511u;
+    const uint32_t m3 = t3 - (k9 << 23);
+    const uint64_t x1 = (uint64_t)t1 * 407u, x2 = (uint64_t)t2 * 407u, x3 = (uint64_t)m3 * 407u;
+    uint32_t u0 = (uint32_t)x0, u1, u2, u3, u4;
+    u1 = fp_addc((uint32_t)(x0 >> 32), (uint32_t)x1, 0, &cy);
+    u2 = fp_addc((uint32_t)x2, (uint32_t)(x1 >> 32), cy, &cy);
+    u3 = fp_addc((uint32_t)(x2 >> 32), (uint32_t)x3, cy, &cy);
+    u4 = (uint32_t)(x3 >> 32) + cy;
+    const uint32_t cq = ((m3 >> 23) + (u0 & 511u)) >> 9;
+    uint32_t q0 = __builtin_amdgcn_alignbit(u1, u0, 9), q1 = __builtin_amdgcn_alignbit(u2, u1, 9), q2 = __builtin_amdgcn_alignbit(u3, u2, 9), q3 = __builtin_amdgcn_alignbit(u4, u3, 9);
+    uint32_t bw, r0, r1, r2, r3;
+    r0 = fp_subc(t4, q0, cq, &bw); r1 = fp_subc(t5, q1, bw, &bw); r2 = fp_subc(t6, q2, bw, &bw); r3 = fp_subc(t7, q3, bw, &bw);
+    const uint32_t m3p = bw ? FP_P3 : 0u;
+    r0 = fp_addc(r0, 0u, bw, &cy); r1 = fp_addc(r1, 0, cy, &cy); r2 = fp_addc(r2, 0, cy, &cy); r3 = r3 + m3p + cy;
+    return fp_make(r0, r1, r2, r3);
+}
+
+#else
+__device__ __forceinline__ fp mont_mul_dev(fp a, fp b) { return mont_mul_dev_eo(a, b); }
+#endif
 #endif
 FP_HD fp mont_mul(fp a, fp b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(FP_MONT_MUL_C)

@@ -148,3 +148,5 @@ hipError_t launch_round_wg(bool fold, const fp* cw, fp* out, uint32_t log_half, 
                            uint32_t* h_abort, uint64_t timeout_ticks, const fp* tw_inv, uint32_t log_n_table, uint32_t tw_shift, digest64* sub_out,
                            uint64_t* rec_roots, uint32_t* rec_seq, uint32_t* counter, uint32_t target, hipStream_t s);
 #define ROUND_WG_MAX_LOG_TOTAL 15
+#define ROUND_WG_MAX_LOG_LIMIT 18              // what k_round_wg's indexing allows; STARK_HIP_ROUND_WG_MAX_LOG picks the threshold in use (A/B)
+uint32_t round_wg_max_log();                   // round_kernels.hip

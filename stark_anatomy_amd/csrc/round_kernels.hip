@@ -134,12 +134,16 @@ __global__ __launch_bounds__(RW_THREADS) void k_round_wg(const RoundArgs a) {
         for (uint32_t i = tid; i < nout * 8; i += RW_THREADS) a.sub_out[(size_t)blockIdx.x * nout + (i >> 3)].h[i & 7] = sm[s_off + QR_DIGEST_OFF(i >> 3) + (i & 7)];
 }
 
-// Returns hipErrorInvalidValue unless B·2^log_half <= 2^15.
+uint32_t round_wg_max_log() {
+    static const uint32_t v = [] { const char* e = getenv("STARK_HIP_ROUND_WG_MAX_LOG"); const int x = e ? atoi(e) : 0; return (uint32_t)(x >= 7 && x <= ROUND_WG_MAX_LOG_LIMIT ? x : ROUND_WG_MAX_LOG_TOTAL); }();
+    return v;
+}
+// Returns hipErrorInvalidValue unless B·2^log_half <= 2^round_wg_max_log() (2^15 by default).
 hipError_t launch_round_wg(bool fold, const fp* cw, fp* out, uint32_t log_half, size_t B, const uint32_t* h_seq, uint32_t gen, const fp* h_c0, const fp* d_c0, uint32_t* d_abort,
                            uint32_t* h_abort, uint64_t timeout_ticks, const fp* tw_inv, uint32_t log_n_table, uint32_t tw_shift, digest64* sub_out,
                            uint64_t* rec_roots, uint32_t* rec_seq, uint32_t* counter, uint32_t target, hipStream_t s) {
     const size_t total = B << log_half;
-    if (!B || total > ((size_t)1 << ROUND_WG_MAX_LOG_TOTAL) || log_half == 0 || log_half > ROUND_WG_MAX_LOG_TOTAL) return hipErrorInvalidValue;
+    if (!B || total > ((size_t)1 << round_wg_max_log()) || log_half == 0 || log_half > round_wg_max_log()) return hipErrorInvalidValue;
     if (log_half > RW_CHUNK_LOG && !sub_out) return hipErrorInvalidValue;
     if (log_half <= RW_CHUNK_LOG && total > RW_CHUNK && !counter && !sub_out) return hipErrorInvalidValue;    // roots of several workgroups need one of the two ways out
     const unsigned blocks = (unsigned)((total + RW_CHUNK - 1) / RW_CHUNK);

@@ -6,7 +6,11 @@
 #include <vector>
 #include "fp128.cuh"
 
-template <int V> __device__ __forceinline__ fp mm(fp a, fp b) { return V == 0 ? mont_mul_c(a, b) : mont_mul(a, b); }
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int V> __device__ __forceinline__ fp mm(fp a, fp b) { return V == 0 ? mont_mul_c(a, b) : V == 1 ? mont_mul_dev_eo(a, b) : mont_mul(a, b); }
+#else
+template <int V> __device__ __forceinline__ fp mm(fp a, fp b) { return mont_mul_c(a, b); }
+#endif
 
 template <int V>
 __global__ __launch_bounds__(256) void k_chain(const fp* __restrict__ in, fp* __restrict__ out, int iters) {
@@ -38,27 +42,32 @@ int main() {
     hipMalloc(&da, n * 16); hipMalloc(&db, n * 16); hipMalloc(&d0, n * 16); hipMalloc(&d1, n * 16);
     hipMemcpy(da, a.data(), n * 16, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), n * 16, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_pairs<0>, dim3(n / 256), dim3(256), 0, 0, da, db, d0, n);
+    fp* d2; hipMalloc(&d2, n * 16);
+    std::vector<fp> o2(n);
     hipLaunchKernelGGL(k_pairs<1>, dim3(n / 256), dim3(256), 0, 0, da, db, d1, n);
+    hipLaunchKernelGGL(k_pairs<2>, dim3(n / 256), dim3(256), 0, 0, da, db, d2, n);
+    hipMemcpy(o2.data(), d2, n * 16, hipMemcpyDeviceToHost);
     hipMemcpy(o0.data(), d0, n * 16, hipMemcpyDeviceToHost); hipMemcpy(o1.data(), d1, n * 16, hipMemcpyDeviceToHost);
     size_t bad = 0, bad_host = 0;
     for (size_t i = 0; i < n; ++i) {
-        if (!fp_eq(o0[i], o1[i])) ++bad;
+        if (!fp_eq(o0[i], o1[i]) || !fp_eq(o0[i], o2[i])) ++bad;
         if (i < (1 << 16) && !fp_eq(o0[i], mont_mul_c(a[i], b[i]))) ++bad_host;
     }
-    printf("pairs: %zu of %zu differ between the C form and the device form; %zu of 65536 differ from the host\n", bad, n, bad_host);
+    printf("pairs: %zu of %zu differ between the C form and the two device forms; %zu of 65536 differ from the host\n", bad, n, bad_host);
     const int iters = 256;
     const size_t lanes = (size_t)256 * 8 * 256;             // 8 workgroups of 256 per CU
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < 3; ++v) {
         float best = 1e9f;
         for (int rep = 0; rep < 4; ++rep) {
             hipEventRecord(e0);
             if (v == 0) hipLaunchKernelGGL(k_chain<0>, dim3(lanes / 256), dim3(256), 0, 0, da, d0, iters);
-            else hipLaunchKernelGGL(k_chain<1>, dim3(lanes / 256), dim3(256), 0, 0, da, d1, iters);
+            else if (v == 1) hipLaunchKernelGGL(k_chain<1>, dim3(lanes / 256), dim3(256), 0, 0, da, d1, iters);
+            else hipLaunchKernelGGL(k_chain<2>, dim3(lanes / 256), dim3(256), 0, 0, da, d1, iters);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
         }
-        printf("%-28s %8.3f ms  %7.1f G mont_mul/s\n", v == 0 ? "mont_mul_c (plain C)" : "mont_mul (device form)", best, (double)lanes * 4 * iters / best / 1e6);
+        printf("%-28s %8.3f ms  %7.1f G mont_mul/s\n", v == 0 ? "mont_mul_c (plain C)" : v == 1 ? "even/odd columns (71 VALU)" : "product scanning (61 VALU)", best, (double)lanes * 4 * iters / best / 1e6);
     }
     hipMemcpy(o0.data(), d0, lanes * 4 * 16, hipMemcpyDeviceToHost); hipMemcpy(o1.data(), d1, lanes * 4 * 16, hipMemcpyDeviceToHost);
     bad = 0;
