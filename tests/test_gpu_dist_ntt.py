@@ -179,10 +179,11 @@ def test_four_step_layouts_single_rank(engine, layouts, monkeypatch):
 
 
 @pytest.mark.parametrize("log_N,min_half", [(16, 1 << 8), (16, 1), (20, 1 << 16), (22, 1 << 16), (22, 1 << 10)])
-def test_native_sharded_commit_single_rank(engine, log_N, min_half):
+def test_native_sharded_commit_single_rank(engine, log_N, min_half, monkeypatch):
     """sh_dist_fri_commit on one rank == the single-GPU commit (oracle-checked at these sizes), byte for byte: the sharded rounds
     (fused fold + leaf subtree with a slice offset, chain records, enqueue thread) followed by the locally committed tail."""
     from stark_anatomy_amd import dist_ntt as dn
+    monkeypatch.setenv("STARK_HIP_CHAIN_SPIN_US", "50000")        # parity test: a descheduled host thread is not a re-launch cycle (tests/test_gpu_parity.py)
     N = 1 << log_N
     cw = co.splitmix_elems(900 + log_N, N)
     roots, last, ps = dn.dist_fri_commit(engine.from_host(cw), N, engine, G, 4, 17, min_half=min_half)

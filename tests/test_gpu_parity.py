@@ -481,10 +481,13 @@ def test_fri_commit_batch_vs_oracle(ctx, B, log_n):
     co.set_threads(1)
 
 
-def test_two_codewords_of_2_24_as_two_groups(ctx):
+def test_two_codewords_of_2_24_as_two_groups(ctx, monkeypatch):
     """2 x 2^24 (bench.py's throughput leg at the metric's large size): the batch call runs the two commits as two groups of
     one on two streams; roots, last codewords and stream bytes must equal two single commits of the same device data (the
-    single 2^24 commit is oracle-checked in test_c5_full_size_2_24_vs_oracle)."""
+    single 2^24 commit is oracle-checked in test_c5_full_size_2_24_vs_oracle).  A parity test: the GPU-side wait gets a generous
+    spin budget, so that a host thread descheduled for a millisecond on a shared box is not mistaken for a re-launch cycle (the
+    default budget is exercised by test_commit_while_another_thread_allocates_and_frees and test_two_contexts_in_two_threads)."""
+    monkeypatch.setenv("STARK_HIP_CHAIN_SPIN_US", "50000")
     log_n = 24
     N = 1 << log_n
     d = ctx.alloc(2 * N * 16)
@@ -548,30 +551,36 @@ def test_two_contexts_in_two_threads():
         cw = co.splitmix_elems(seed, 1 << log_n)
         r, _, l, ps = co.fri_commit(cw, 4, 17, G)
         exp[seed] = (cw, r, l, ps.serialize(), co.ntt(cw[: 1 << 12]))
-    errors = []
+    def attempt():
+        errors, retries = [], []
 
-    def worker(seed, log_n):
-        try:
-            c = sa.Context(0)
-            cw, r, l, ser, ntt_exp = exp[seed]
-            for _ in range(6):
-                ps = sa.ProofStream()
-                roots, last = sa.Fri(G, None, 1 << log_n, 4, 17, ctx=c).commit(cw, ps)
-                assert [h.as_bytes() for h in roots] == r and np.array_equal(last, l) and ps.serialize() == ser
-                assert np.array_equal(sa.ntt(cw[: 1 << 12], ctx=c), ntt_exp)
-            retries.append(c.chain_retries)
-            c.close()
-        except Exception as e:  # surfaced in the main thread
-            errors.append(e)
-    retries = []
-    th = [threading.Thread(target=worker, args=j) for j in jobs]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    assert not errors, errors
+        def worker(seed, log_n):
+            try:
+                c = sa.Context(0)
+                cw, r, l, ser, ntt_exp = exp[seed]
+                for _ in range(6):
+                    ps = sa.ProofStream()
+                    roots, last = sa.Fri(G, None, 1 << log_n, 4, 17, ctx=c).commit(cw, ps)
+                    assert [h.as_bytes() for h in roots] == r and np.array_equal(last, l) and ps.serialize() == ser
+                    assert np.array_equal(sa.ntt(cw[: 1 << 12], ctx=c), ntt_exp)
+                retries.append(c.chain_retries)
+                c.close()
+            except Exception as e:  # surfaced in the main thread
+                errors.append(e)
+        th = [threading.Thread(target=worker, args=j) for j in jobs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        return retries
     # the thread that serves a commit's chain makes no HIP call while a kernel waits for it: no wait kernel
-    # may have run out of spin, at the default budget
+    # may have run out of spin, at the default budget.  The cycle this guards against re-launched rounds in EVERY run (round 2);
+    # a serving thread that the OS takes off its core for longer than the 500 us budget on a shared box does so once in a blue
+    # moon — so a run with re-launches is repeated once, and the repeat must be clean.
+    retries = attempt()
+    if retries != [0, 0]:
+        retries = attempt()
     assert retries == [0, 0], retries
 
 
@@ -621,41 +630,47 @@ def test_commit_while_another_thread_allocates_and_frees():
     cw = co.splitmix_elems(31, 1 << log_n)
     r, _, l, ps_exp = co.fri_commit(cw, 4, 17, G)
     ser = ps_exp.serialize()
-    stop = threading.Event()
-    errors = []
+    def attempt():
+        stop = threading.Event()
+        errors = []
 
-    def churn():
+        def churn():
+            try:
+                c2 = sa.Context(0)
+                while not stop.is_set():
+                    bufs = [c2.alloc(1 << 20) for _ in range(4)]
+                    for b in bufs:
+                        b.free()
+                c2.close()
+            except Exception as e:
+                errors.append(e)
+        t = threading.Thread(target=churn)
+        t.start()
+        c = sa.Context(0)
         try:
-            c2 = sa.Context(0)
-            while not stop.is_set():
-                bufs = [c2.alloc(1 << 20) for _ in range(4)]
-                for b in bufs:
-                    b.free()
-            c2.close()
-        except Exception as e:
-            errors.append(e)
-    t = threading.Thread(target=churn)
-    t.start()
-    c = sa.Context(0)
-    try:
-        for _ in range(40):
-            ps = sa.ProofStream()
-            roots, last = sa.Fri(G, None, 1 << log_n, 4, 17, ctx=c).commit(cw, ps)
-            assert [h.as_bytes() for h in roots] == r and np.array_equal(last, l) and ps.serialize() == ser
-        retries = c.chain_retries
-    finally:
-        stop.set()
-        t.join()
-        c.close()
-    assert not errors, errors
+            for _ in range(40):
+                ps = sa.ProofStream()
+                roots, last = sa.Fri(G, None, 1 << log_n, 4, 17, ctx=c).commit(cw, ps)
+                assert [h.as_bytes() for h in roots] == r and np.array_equal(last, l) and ps.serialize() == ser
+            retries = c.chain_retries
+        finally:
+            stop.set()
+            t.join()
+            c.close()
+        assert not errors, errors
+        return retries
+    retries = attempt()
+    if retries:                                   # a descheduled serving thread, or the cycle?  The cycle repeats (see test_two_contexts_in_two_threads)
+        retries = attempt()
     assert retries == 0, f"{retries} rounds were enqueued a second time"
 
 
-def test_commit_after_commit_of_another_shape_on_one_context():
+def test_commit_after_commit_of_another_shape_on_one_context(monkeypatch):
     """The chain's record layout depends on (B, R), so the sequence words of one commit lie where an earlier commit of
     another shape staged data.  A one-round commit of N = 128 stages its own codeword in the chain buffer; with every element
     equal to the NEXT commit's generation number those bytes read as "published" to a driver that does not lower its
     sequence words first: the larger commit that follows must still produce the oracle's roots."""
+    monkeypatch.setenv("STARK_HIP_CHAIN_SPIN_US", "50000")        # a stale "published" word would show as wrong roots, not as a retry; see the note in test_two_codewords_of_2_24_as_two_groups
     for first_val in (2, 3):                       # generation of the second / third commit on a fresh context
         c = sa.Context(0)
         try:
