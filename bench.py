@@ -264,8 +264,10 @@ def main():
         def e2e():
             _lib.check(_lib.lib.sh_dev_coset_lde(H, d_coef.ptr, log_n - 2, 2, _u64p(scalar(sa.GENERATOR)), d_x.ptr))
             commit(d_x, N)
-        dt_e2e = timed(e2e, max(3, args.steps // 2), 1)
-        extra[f"lde_plus_commit_2^{log_n}_elems_per_s"] = world * N * max(3, args.steps // 2) / dt_e2e
+        e2e_steps = max(5, args.steps)
+        dt_e2e = timed(e2e, e2e_steps, 2)
+        extra[f"lde_plus_commit_2^{log_n}_elems_per_s"] = world * N * e2e_steps / dt_e2e
+        extra[f"lde_plus_commit_2^{log_n}_ms"] = 1e3 * dt_e2e / e2e_steps
         d_x.free(); d_coef.free()
 
         # ---- BASELINE config 4 (per-GPU share): 128 independent 2^14 commits in lock step ----

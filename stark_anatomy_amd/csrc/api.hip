@@ -374,9 +374,17 @@ int32_t sh_dev_coset_lde_batch(sh_ctx* c, const uint64_t* d_coeffs, size_t batch
     SHCHK(ensure_scratch(c, SCR_LDE_TAB, (sh.rows + sh.chunks + sh.cols) * sizeof(fp), &tab));
     fp* pow_row = (fp*)tab, *pow_chunk = pow_row + sh.rows, *pow_col = pow_chunk + sh.chunks;
     auto pow2k = [&](uint32_t k) { fp b = fp_to_mont(off); for (uint32_t i = 0; i < k; ++i) b = mont_mul(b, b); return b; };   // offset^(2^k), Montgomery form
-    HIPCHK(launch_pow_table(pow_row, sh.rows, pow2k(sh.log_row_stride), c->stream));
-    HIPCHK(launch_pow_table(pow_chunk, sh.chunks, pow2k(sh.log_cols), c->stream));
-    HIPCHK(launch_pow_table(pow_col, sh.cols, pow2k(0), c->stream));
+    const sh_ctx::LdeTabKey key{{offset[0], offset[1]}, sh.rows, sh.chunks, sh.cols, sh.log_row_stride, sh.log_cols, tab};
+    const sh_ctx::LdeTabKey& have = c->lde_tab_key;
+    const bool cached = have.ptr == key.ptr && have.off[0] == key.off[0] && have.off[1] == key.off[1] && have.rows == key.rows && have.chunks == key.chunks &&
+                        have.cols == key.cols && have.log_row_stride == key.log_row_stride && have.log_cols == key.log_cols;
+    if (!cached) {                                     // same coset, same shape as the last call on this context (same stream): the tables are still there
+        c->lde_tab_key = sh_ctx::LdeTabKey{};
+        HIPCHK(launch_pow_table(pow_row, sh.rows, pow2k(sh.log_row_stride), c->stream));
+        HIPCHK(launch_pow_table(pow_chunk, sh.chunks, pow2k(sh.log_cols), c->stream));
+        HIPCHK(launch_pow_table(pow_col, sh.cols, pow2k(0), c->stream));
+        c->lde_tab_key = key;
+    }
     const NttLdeFuse fuse{(const fp*)d_coeffs, log_expansion, pow_row, pow_chunk, pow_col};
     NttPassTables ptab;
     SHCHK(get_pass_tables(c, plan, false, tw, &ptab));

@@ -192,6 +192,9 @@ struct sh_ctx {
     bool mail_pending = false;                   // the root of the last reduction arrives through the mailbox
     uint64_t mail_fallbacks = 0;
     std::map<uint32_t, fp*> tw_cache;            // key = log_n*2 + inverse
+    // the fused LDE's three power tables (SCR_LDE_TAB) as last built: a prover extends polynomial after polynomial onto one coset, and the
+    // three k_pow_table launches are a fifth of a 128 x 2^12 -> 2^14 batch's time
+    struct LdeTabKey { uint64_t off[2]; size_t rows, chunks, cols; uint32_t log_row_stride, log_cols; void* ptr; } lde_tab_key = {};
     std::map<uint32_t, fp*> ptw_cache;           // direct inter-pass twiddle tables: key = (log_n*2 + inverse)*NTT_MAX_PASSES + pass
     uint8_t* h_batch = nullptr;                  // pinned, device-mapped staging for batched commits: roots (B*64) | c0 (B*16)
     uint8_t* d_hbatch = nullptr;                 // device view of h_batch

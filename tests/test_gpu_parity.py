@@ -248,6 +248,14 @@ def test_lde_golden_and_oracle(ctx, golden):
         assert (sa.coset_lde(c, le, off, ctx=ctx) == co.coset_lde(c, le, off)).all()
 
 
+def test_lde_power_tables_are_cached_per_coset_and_shape(ctx):
+    """The fused LDE keeps its three offset-power tables from the last call on the context (api.hip: lde_tab_key) and rebuilds them
+    when the coset or the tile shape changes: A, A again (cached), B (rebuilt), A (rebuilt), another size, back — all against the oracle."""
+    c12, c13 = co.splitmix_elems(61, 1 << 12), co.splitmix_elems(62, 1 << 13)
+    for coeffs, le, off in ((c12, 2, G), (c12, 2, G), (c12, 2, 12345), (c12, 2, G), (c13, 2, G), (c12, 2, G), (c12, 3, G), (c12, 2, G)):
+        assert np.array_equal(sa.coset_lde(coeffs, le, off, ctx=ctx), co.coset_lde(coeffs, le, off))
+
+
 @pytest.mark.parametrize("batch,log_n,log_e", [(5, 3, 2), (3, 10, 2), (128, 12, 2), (7, 12, 3), (2, 16, 0), (4, 9, 1), (1, 18, 2)])
 def test_lde_batch_equals_single_and_oracle(ctx, batch, log_n, log_e):
     """sh_dev_coset_lde_batch: `batch` polynomials back to back through one launch per pass == one sh_dev_coset_lde each
