@@ -62,6 +62,7 @@ int32_t get_pass_tables(sh_ctx* c, const NttPlan& plan, bool inverse, const fp* 
     static const uint32_t max_log = [] { const char* e = getenv("STARK_HIP_NTT_PASS_TW_LOG"); const int v = e ? atoi(e) : 20; return (uint32_t)(v < 0 ? 0 : v > 26 ? 26 : v); }();
     uint32_t consumed = 0;
     for (uint32_t pi = 0; pi < NTT_MAX_PASSES; ++pi) out->t[pi] = nullptr;
+    out->scale_folded = false;
     for (uint32_t pi = 0; pi + 1 < plan.num_passes; ++pi) {
         const uint32_t log_m = plan.log_n - consumed;
         consumed += plan.bits[pi];
@@ -73,8 +74,14 @@ int32_t get_pass_tables(sh_ctx* c, const NttPlan& plan, bool inverse, const fp* 
             HIPCHK(hipMalloc(&d, ((size_t)1 << log_m) * sizeof(fp)));
             const hipError_t e = launch_pass_twiddles(d, tw, plan.log_n, log_m, plan.bits[pi], c->stream);
             if (e != hipSuccess) { (void)hipFree(d); return sh_failf(SH_EHIP, "pass twiddle table: %s", hipGetErrorString(e)); }
+            if (inverse && pi + 2 == plan.num_passes) {            // the inverse transform's 1/n: every element passes this table exactly once
+                const fp n_inv = fp_to_mont(fp_inv(fp_from_u64x2((uint64_t)1 << plan.log_n, 0)));
+                const hipError_t e2 = launch_scale_powers(d, (size_t)1 << log_m, n_inv, fp_one(), c->stream);
+                if (e2 != hipSuccess) { (void)hipFree(d); return sh_failf(SH_EHIP, "pass twiddle table: %s", hipGetErrorString(e2)); }
+            }
             it = c->ptw_cache.emplace(key, d).first;
         }
+        if (inverse && pi + 2 == plan.num_passes) out->scale_folded = true;
         out->t[pi] = it->second;
     }
     return SH_OK;
@@ -259,7 +266,7 @@ int32_t dev_ntt(sh_ctx* c, fp* d_data, uint32_t log_n, bool inverse, size_t batc
     if (inverse) scale = fp_to_mont(fp_inv(fp_from_u64x2((uint64_t)1 << log_n, 0)));
     NttPassTables ptab;
     SHCHK(get_pass_tables(c, plan, inverse, tw, &ptab));
-    HIPCHK(launch_ntt(plan, d_data, (fp*)scratch, tw, scale, inverse, batch, c->stream, nullptr, &ptab));
+    HIPCHK(launch_ntt(plan, d_data, (fp*)scratch, tw, scale, inverse && !ptab.scale_folded, batch, c->stream, nullptr, &ptab));
     return SH_OK;
 }
 

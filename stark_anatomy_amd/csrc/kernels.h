@@ -77,7 +77,7 @@ hipError_t launch_pow_table(fp* out, size_t count, fp base_mont, hipStream_t s);
 // Direct tables of a transform's inter-pass twiddles: t[pi][(k << log_cols_pi) + col] = w_m^(col·k) for the non-final pass pi
 // (m = the pass's sub-block length, col < m/R, k < R), or null: the pass then builds each twiddle from the two-level table
 // (one more multiply per element).
-struct NttPassTables { const fp* t[NTT_MAX_PASSES]; };
+struct NttPassTables { const fp* t[NTT_MAX_PASSES]; bool scale_folded; };   // scale_folded: an inverse transform's 1/n rides in the last non-final pass's table
 hipError_t launch_pass_twiddles(fp* out, const fp* tw, uint32_t log_n, uint32_t log_m, uint32_t log_r, hipStream_t s);
 hipError_t launch_ntt(const NttPlan& plan, fp* data, fp* scratch, const fp* tw, fp scale_mont, bool apply_scale, size_t batch, hipStream_t s, const NttLdeFuse* fuse = nullptr,
                       const NttPassTables* ptab = nullptr);
