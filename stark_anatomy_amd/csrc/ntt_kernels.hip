@@ -15,6 +15,11 @@
 // Butterflies are decimation-in-frequency, so rows come out bit-reversed and the reversal is
 // absorbed into the store address.  Twiddles come from a two-level table of Montgomery-form powers
 // (4096 + n/4096 entries, L2-resident): w^e = lo[e & 4095]·hi[e >> 12].
+// Two forms of a pass.  k_ntt_pass_reg (default wherever a pass has 2^6, 2^7 or 2^8 rows and 16-column tiles, i.e. every pass of
+// every transform from 2^12 up except 2^17's last): four butterfly levels per wave in registers, row bits moved between
+// registers and lanes with v_permlane32_swap / v_permlane16_swap, ONE trip through LDS per tile — see the comment above that
+// kernel.  k_ntt_pass (all other shapes, and everything under STARK_HIP_NTT_REG=0): the tile stays in LDS for all its levels,
+// two levels per LDS round trip.  Same bits either way (tests/test_gpu_parity.py::test_ntt_register_exchange_pass_matches_lds_pass).
 // mont_mul is the asm form of fp128.cuh (a third fewer instructions).  Round 2 first kept the plain-C form here: with the asm
 // form k_ntt_pass took 79 VGPRs and a 1024-lane workgroup no longer fitted twice on a CU (1.16 ms against 1.005 at 2^24).
 // Since the last level group is a specialisation of its own (ntt_levels<S, true>) the kernel needs 60, and the asm form
