@@ -184,6 +184,22 @@ def test_ntt_edge_values(ctx):
         assert (sa.ntt(x, ctx=ctx) == co.ntt(x)).all()
 
 
+@pytest.mark.parametrize("log_n", [12, 13, 16])
+def test_ntt_edge_values_register_exchange_sizes(ctx, log_n):
+    """The same extreme operands at sizes whose passes run in the register-exchange form (2^12 = 6+6, 2^13 = 7+6, 2^16 = 8+8 rows):
+    all p-1 (every butterfly sum carries past 2^128), all zero, alternating 0 / p-1, and the edge table repeated; forward, inverse
+    and the fused LDE against the oracle."""
+    n = 1 << log_n
+    edge = (EDGE * (n // len(EDGE) + 1))[:n]
+    for vals in ([P - 1] * n, [0] * n, [(P - 1) if i % 2 else 0 for i in range(n)], [(P - 1) if (i >> 6) % 2 else 1 for i in range(n)], edge):
+        x = co.to_arr(vals)
+        assert (sa.ntt(x, ctx=ctx) == co.ntt(x)).all()
+        assert (sa.intt(x, ctx=ctx) == co.ntt(x, inverse=True)).all()
+    c = co.to_arr(edge[: n >> 2])
+    assert (sa.coset_lde(c, 2, G, ctx=ctx) == co.coset_lde(c, 2, G)).all()
+    assert (sa.coset_lde(c, 2, P - 1, ctx=ctx) == co.coset_lde(c, 2, P - 1)).all()
+
+
 def test_ntt_large_properties(ctx):
     """2^24 points (the north-star size): INTT(NTT(x)) == x, linearity, and a naive spot check of
     single outputs X[k] = sum_j x[j] w^(jk) for a sparse input."""
