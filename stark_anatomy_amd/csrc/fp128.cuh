@@ -90,6 +90,52 @@ FP_HD fp fp_sub(fp a, fp b) {
     return fp_from_u128(x < y ? d + fp_prime_u128() : d);
 #endif
 }
+// (u + t, u - t) mod p in one block: the three carry chains of a butterfly (the sum, the sum minus p, the difference) interleaved
+// by hand, so that every carry's write and read are two instructions apart without wait-state fillers, the "sum >= p" decision is
+// one scalar or-not of two carry masks, and the difference takes its "+p" as carry-in = borrow: 21 VALU instructions where
+// fp_add + fp_sub compile to 14 + 9 (the compiler turns "subtract 0 with borrow" into a select and a subtract).  Canonical in,
+// canonical out, bit-equal to the pair (tools/mm_bench.hip).  The scalar or-not writes SCC: the clobber list must say so — without
+// it the scheduler parks the block between an s_cmp and its s_cbranch_scc / s_cselect (DESIGN.md section 8 item 3 tells that story).
+__device__ __forceinline__ void fp_butterfly(const fp u, const fp t, fp& sum, fp& diff) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FP_ADDSUB_C) && !defined(FP_BUTTERFLY_C)
+    uint32_t s0, s1, s2, s3, d0, d1, d2, d3, x0, x1, x2, x3, m3;
+    uint64_t k1, k2, k3, k4;
+    asm("v_add_co_u32_e64 %[s0], %[k1], %[u0], %[t0]\n\t"
+        "v_sub_co_u32_e64 %[x0], %[k3], %[u0], %[t0]\n\t"
+        "v_subrev_co_u32_e64 %[d0], %[k2], 1, %[s0]\n\t"
+        "v_addc_co_u32_e64 %[s1], %[k1], %[u1], %[t1], %[k1]\n\t"
+        "v_subb_co_u32_e64 %[x1], %[k3], %[u1], %[t1], %[k3]\n\t"
+        "v_subbrev_co_u32_e64 %[d1], %[k2], 0, %[s1], %[k2]\n\t"
+        "v_addc_co_u32_e64 %[s2], %[k1], %[u2], %[t2], %[k1]\n\t"
+        "v_subb_co_u32_e64 %[x2], %[k3], %[u2], %[t2], %[k3]\n\t"
+        "v_subbrev_co_u32_e64 %[d2], %[k2], 0, %[s2], %[k2]\n\t"
+        "v_addc_co_u32_e64 %[s3], %[k1], %[u3], %[t3], %[k1]\n\t"
+        "v_subb_co_u32_e64 %[x3], %[k3], %[u3], %[t3], %[k3]\n\t"
+        "v_subb_co_u32_e64 %[d3], %[k2], %[s3], %[p3], %[k2]\n\t"
+        "s_orn2_b64 vcc, %[k1], %[k2]\n\t"                                  // sum left 128 bits, or did not go below p  (writes SCC)
+        "v_cndmask_b32_e64 %[m3], 0, %[p3], %[k3]\n\t"
+        "v_addc_co_u32_e64 %[x0], %[k4], 0, %[x0], %[k3]\n\t"               // difference negative: + p = + borrow on limb 0 ...
+        "v_cndmask_b32_e32 %[s0], %[s0], %[d0], vcc\n\t"
+        "v_cndmask_b32_e32 %[s1], %[s1], %[d1], vcc\n\t"
+        "v_addc_co_u32_e64 %[x1], %[k4], 0, %[x1], %[k4]\n\t"
+        "v_cndmask_b32_e32 %[s2], %[s2], %[d2], vcc\n\t"
+        "v_cndmask_b32_e32 %[s3], %[s3], %[d3], vcc\n\t"
+        "v_addc_co_u32_e64 %[x2], %[k4], 0, %[x2], %[k4]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[x3], %[k4], %[x3], %[m3], %[k4]\n\t"           // ... and the masked top limb
+        : [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2), [s3] "=&v"(s3), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3),
+          [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [m3] "=&v"(m3),
+          [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3), [k4] "=&s"(k4)
+        : [u0] "v"(u.w[0]), [u1] "v"(u.w[1]), [u2] "v"(u.w[2]), [u3] "v"(u.w[3]), [t0] "v"(t.w[0]), [t1] "v"(t.w[1]), [t2] "v"(t.w[2]), [t3] "v"(t.w[3]),
+          [p3] "v"(FP_P3)
+        : "vcc", "scc");
+    sum = fp_make(s0, s1, s2, s3);
+    diff = fp_make(x0, x1, x2, x3);
+#else
+    sum = fp_add(u, t);
+    diff = fp_sub(u, t);
+#endif
+}
 FP_HD fp fp_neg(fp a) { return fp_is_zero(a) ? a : fp_from_u128(fp_prime_u128() - fp_to_u128(a)); }
 // a / 2 mod p
 FP_HD fp fp_half(fp a) {

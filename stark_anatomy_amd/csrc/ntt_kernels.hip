@@ -96,8 +96,8 @@ __device__ __forceinline__ void ntt_levels(fp* __restrict__ x, const fp* __restr
             for (int e = 0; e < (1 << S); ++e) {
                 if (e & (1 << s)) continue;
                 const fp u = v[e], t = v[e | (1 << s)];
-                v[e] = fp_add(u, t);
-                fp d = fp_sub(u, t);
+                fp d;
+                fp_butterfly(u, t, v[e], d);
                 if (LO0 ? (e & ((1 << s) - 1)) != 0 : true) d = mont_mul(d, twr[(r_low + ((uint32_t)(e & ((1 << s) - 1)) << lo)) << sh]);
                 v[e | (1 << s)] = d;
             }
@@ -274,8 +274,8 @@ __device__ __forceinline__ void ntt_radix4(fp (&v)[4], const fp* __restrict__ tw
         for (int e = 0; e < 4; ++e) {
             if (e & (1 << s)) continue;
             const fp u = v[e], t = v[e | (1 << s)];
-            v[e] = fp_add(u, t);
-            fp d = fp_sub(u, t);
+            fp d;
+            fp_butterfly(u, t, v[e], d);
             if (LO0 ? (e & ((1 << s) - 1)) != 0 : true) d = mont_mul(d, twr[(r_low + ((uint32_t)(e & ((1 << s) - 1)) << lo)) << sh]);
             v[e | (1 << s)] = d;
         }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(4 << LR, 8) void k_ntt_pass_reg(NttPassParams p) {
         ntt_radix4<LR, false>(v, twr, b0, 1);
         ntt_swap_lo(v);                                           // now register bit 0 = b0, lane bit 4 = b1
 #pragma unroll
-        for (int e = 0; e < 4; e += 2) { const fp u = v[e], w = v[e | 1]; v[e] = fp_add(u, w); v[e | 1] = fp_sub(u, w); }   // level 0: no twiddle
+        for (int e = 0; e < 4; e += 2) { const fp u = v[e], w = v[e | 1]; fp_butterfly(u, w, v[e], v[e | 1]); }   // level 0: no twiddle
 #pragma unroll
         for (int e = 0; e < 4; ++e) rows[e] = (wave << 4) | (b3 << 3) | ((uint32_t)(e >> 1) << 2) | (b0 << 1) | (uint32_t)(e & 1);   // lane bit 4 now holds b1
     } else {                                                      // LR == 6: e = (b1, b0), t = (b3, b2)
